@@ -1,0 +1,116 @@
+/*
+ * basd_hip.h -- C-ABI of the MI355X (gfx950) BASD loss-path kernels.
+ *
+ * Every entry takes raw DEVICE pointers, explicit shapes and a hipStream_t
+ * (passed as void*), never allocates / frees / synchronises the device, and
+ * returns an int status (0 = ok).  basd_last_error() returns a thread-local
+ * message for the last non-zero status.  No C++ exception crosses this
+ * boundary, no torch type appears in any signature.
+ *
+ * The reference project is pure Python and has no FFI layer; the entries
+ * below replace the library calls its loss path makes (citations are
+ * file:line in the reference repository):
+ *
+ *   basd_token_gram        src/losses/layer_selector.py:72,135 (projection GEMM)
+ *                          + :13 (X^T X) + :35 (column mean)
+ *   basd_pchol_f64 +
+ *   basd_jacobi_svd        torch.linalg.eigvalsh  layer_selector.py:16
+ *                          torch.linalg.svd       layer_selector.py:36,92
+ *                          torch.linalg.svdvals   layer_selector.py:99
+ *                          matrix_norm(ord="nuc") src/losses/relational.py:48
+ *   basd_mp_rank           layer_selector.py:17-20 (.median/.sum, on device, no .item())
+ *   basd_mix_tokens        layer_selector.py:110-112 (+ torch.stack :128-129 eliminated)
+ *   basd_procrustes_prep   src/losses/relational.py:29-46, src/losses/combined.py:9-14
+ *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
+ */
+#ifndef BASD_HIP_H
+#define BASD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BASD_OK 0
+#define BASD_ERR_SHAPE 1        /* bad / unsupported shape                       */
+#define BASD_ERR_LAUNCH 2       /* HIP launch error                              */
+#define BASD_ERR_WORKSPACE 3    /* workspace too small                           */
+#define BASD_ERR_DTYPE 4        /* unsupported dtype code                        */
+
+#define BASD_DTYPE_F32 0
+#define BASD_DTYPE_BF16 1
+
+/* largest matrix the LDS-resident Jacobi accepts: cols * ld(rows) * 4 <= 160 KiB - scratch */
+#define BASD_JACOBI_MAX_COLS 256
+#define BASD_JACOBI_LDS_BYTES 163840
+
+int basd_version(void);
+const char* basd_last_error(void);
+
+/* z = X P^T (fp32 MFMA), gram = z^T z and colsum = 1^T z accumulated in fp64.
+ * x: [rows, d_in] row-major (dtype code), proj: [d_out, d_in] fp32 row-major,
+ * gram: [d_out, d_out] fp64 (MUST be zeroed by the caller), colsum: [d_out] fp64 (zeroed).
+ * d_out <= 256 and d_out % 16 == 0; d_in % 16 == 0. */
+int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in,
+                    const float* proj, int d_out,
+                    double* gram, double* colsum, void* stream);
+
+/* Pivoted (diagonal pivoting) Cholesky of `batch` symmetric PSD fp64 matrices
+ * a[b] (n x n).  Writes
+ *   w0   [batch, n, ld] fp32: column k (contiguous, ld floats) = k-th Cholesky column,
+ *        rows in ORIGINAL order (a[b] = W0 W0^T), columns >= rank zeroed;
+ *   lwork[batch, n, n] fp64: the same columns in fp64 (column-major by step);
+ *   piv  [batch, n] int32: pivot row chosen at step k (a permutation of 0..n-1);
+ *   rank [batch] int32: number of pivots > tol * max diag.
+ * n <= 256. */
+int basd_pchol_f64(const double* a, int batch, int n, double tol,
+                   float* w0, int ld, double* lwork, int32_t* piv, int32_t* rank,
+                   void* stream);
+
+/* One-sided (Hestenes) Jacobi in LDS on `batch` column-major matrices
+ * w[b]: n_cols columns of `ld` floats, first m_rows rows significant
+ * (rows m_rows..ld-1 must be zero).  Columns are orthogonalised in place;
+ * on return column c holds sigma_c * u_c.  If sort != 0 columns are permuted
+ * so that norms descend.  sigma [batch, n_cols] receives the column norms of
+ * the first `norm_rows` rows (norm_rows = m_rows normally; for a stacked
+ * [A; I] input pass the row count of A so that the bottom block -- the
+ * accumulated right singular vectors -- is excluded from the norm).
+ * sweeps [batch] (optional, may be NULL) receives the sweeps used.
+ * Requires n_cols <= 256, ld % 4 == 0, n_cols * ld * 4 + 4096 <= 160 KiB. */
+int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
+                    float tol, int max_sweeps, int sort,
+                    float* sigma, int32_t* sweeps, void* stream);
+
+/* Marchenko-Pastur rank on device (no host sync).  evals [batch, n] (any order),
+ * rows = M of the [M, D] token matrix, d = D; uses the min(M, D) largest eigenvalues,
+ * LOWER median, lambda_+ = med * (1 + sqrt(D/M))^2, count > lambda_+, clamp to cap. */
+int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int cap,
+                 int32_t* ranks, void* stream);
+
+/* mixed[i] = sum_j w[i, j] * x_j   (all E mixes from ONE pass over the teacher layers)
+ * x_layers: device array of L pointers to [elems] tensors (dtype code), w: [E, L] fp32,
+ * out: [E, elems] fp32. */
+int basd_mix_tokens(const void* const* x_layers, int x_dtype, int L, int E,
+                    const float* w, int64_t elems, float* out, void* stream);
+
+/* Procrustes prep for `batch` = B samples of one extraction point:
+ * s [B, N_s, D_s] (dtype), t [B, N_t, D_t] fp32 (mixed teacher), imp [B, N_t] fp32.
+ * Resamples t and imp to N_s (2-tap linear, align_corners=False), normalises imp,
+ * weighted-centres and sqrt-weights:
+ *   s_w [B, N_s, D_s], t_w [B, N_s, D_t] fp32, a [B, N_s], tr [B, 2] = (tr_s, tr_t). */
+int basd_procrustes_prep(const void* s, int s_dtype, const float* t, const float* imp,
+                         int B, int N_s, int N_t, int D_s, int D_t,
+                         float* s_w, float* t_w, float* a, float* tr, void* stream);
+
+/* dots[i, j] = sum_e g[i, e] * x_j[e]  for all (i, j) from ONE pass over the teacher layers.
+ * g: [E, elems] fp32, dots: [E, L] fp64 (MUST be zeroed by the caller; fp64 atomics keep the
+ * result independent of the arrival order to ~1e-16). */
+int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int L, int E,
+                       const float* g, int64_t elems, double* dots, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASD_HIP_H */

@@ -1,0 +1,172 @@
+"""Kernel-level parity of the C-ABI HIP kernels against fp64 torch references
+(GPU box only).  Tolerances are stated per test."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    import basd_amd._native as native
+    assert torch.cuda.is_available(), "needs an MI355X"
+    native.lib()
+    return native
+
+
+def _colmajor(a: torch.Tensor, ld: int) -> torch.Tensor:
+    """[batch, m, n] row-major matrices -> [batch, n, ld] column-major with zero padded rows."""
+    b, m, n = a.shape
+    w = torch.zeros(b, n, ld, dtype=torch.float32, device=a.device)
+    w[:, :, :m] = a.transpose(1, 2)
+    return w.contiguous()
+
+
+@pytest.mark.parametrize("m,n,batch", [(40, 32, 5), (33, 17, 3), (192, 192, 4), (196, 192, 2), (64, 7, 2)])
+def test_jacobi_singular_values_and_invariants(nat, m, n, batch):
+    g = torch.Generator().manual_seed(m * 1000 + n)
+    a = torch.randn(batch, m, n, generator=g)
+    # graded columns: singular values span ~5 decades
+    a = a * torch.logspace(0, -5, n).view(1, 1, n)
+    ad = a.double()
+    ld = nat.jacobi_ld(m)
+    w = _colmajor(a.cuda(), ld)
+    sigma, sweeps = nat.jacobi_svd(w, m)
+    torch.cuda.synchronize()
+    ref = torch.linalg.svdvals(ad)
+    sig = sigma.cpu().double()
+    # column-graded input: one-sided Jacobi keeps RELATIVE accuracy of every singular value
+    err = float((sig / ref - 1).abs().max())
+    print(f"jacobi {m}x{n}: max rel sigma error {err:.2e}, sweeps {sweeps.tolist()}")
+    assert err < 5e-6
+    wf = w.cpu().double()[:, :, :m].transpose(1, 2)          # [batch, m, n] = U Sigma
+    gram = wf.transpose(1, 2) @ wf
+    off = gram - torch.diag_embed(torch.diagonal(gram, dim1=1, dim2=2))
+    scale = torch.sqrt(torch.diagonal(gram, dim1=1, dim2=2))
+    assert (off / (scale.unsqueeze(1) * scale.unsqueeze(2))).abs().max() < 5e-6
+    # right rotations leave A A^T unchanged
+    aat = ad @ ad.transpose(1, 2)
+    assert torch.allclose(wf @ wf.transpose(1, 2), aat, rtol=0, atol=3e-6 * float(aat.abs().max()))
+    assert int(sweeps.max()) < 40
+    # sorted descending
+    assert bool((sig[:, :-1] >= sig[:, 1:]).all())
+
+
+def test_jacobi_stacked_gives_consistent_right_vectors(nat):
+    k = 24
+    g = torch.Generator().manual_seed(3)
+    q1, _ = torch.linalg.qr(torch.randn(4, 64, k, generator=g))
+    q2, _ = torch.linalg.qr(torch.randn(4, 64, k, generator=g))
+    a = q1.transpose(1, 2) @ q2                      # cosines of principal angles
+    stacked = torch.cat([a, torch.eye(k).expand(4, k, k)], dim=1)   # [4, 2k, k]
+    ld = nat.jacobi_ld(2 * k)
+    w = _colmajor(stacked.cuda(), ld)
+    sigma, _ = nat.jacobi_svd(w, 2 * k, norm_rows=k)
+    out = w.cpu().double()[:, :, :2 * k].transpose(1, 2)
+    us, v = out[:, :k], out[:, k:]
+    sig = sigma.cpu().double()
+    assert torch.allclose(sig, torch.linalg.svdvals(a.double()), rtol=1e-5, atol=1e-7)
+    # A V = U Sigma with V orthogonal
+    assert torch.allclose(a.double() @ v, us, atol=2e-6)
+    assert torch.allclose(v.transpose(1, 2) @ v, torch.eye(k, dtype=torch.float64).expand(4, k, k), atol=2e-6)
+
+
+@pytest.mark.parametrize("n,rank", [(32, 32), (32, 11), (192, 192), (192, 63)])
+def test_pchol_then_jacobi_is_an_eigensolver(nat, n, rank):
+    g = torch.Generator().manual_seed(n + rank)
+    x = torch.randn(3, 4 * n, rank, dtype=torch.float64, generator=g) * torch.logspace(0, -3, rank, dtype=torch.float64)
+    mix = torch.randn(3, rank, n, dtype=torch.float64, generator=g)
+    z = x @ mix
+    a = z.transpose(1, 2) @ z
+    w0, lwork, piv, rk = nat.pchol(a.cuda())
+    torch.cuda.synchronize()
+    assert rk.tolist() == [rank] * 3
+    lw = lwork.cpu().transpose(1, 2)                 # [batch, n(rows), n(steps)]
+    assert torch.allclose(lw @ lw.transpose(1, 2), a, rtol=0, atol=1e-10 * float(a.abs().max()))
+    for b in range(3):
+        assert sorted(piv[b].tolist()) == list(range(n))
+    sigma, _ = nat.jacobi_svd(w0, n)
+    ev = sigma.cpu().double() ** 2
+    ref = torch.linalg.eigvalsh(a).flip(-1)
+    # eigenvalues below 1e-9 * max are beyond what an fp64 Gram matrix resolves to 1e-5
+    ok = ref[:, :rank] > 1e-9 * ref[:, :1]
+    err = float(((ev[:, :rank] / ref[:, :rank] - 1).abs() * ok).max())
+    print(f"pchol+jacobi n={n} rank={rank}: max rel eigenvalue error {err:.2e}")
+    assert err < 1e-5
+    tail = float(ev[:, rank:].abs().max()) if rank < n else 0.0
+    assert tail <= 1e-12 * float(ref.max())
+    # eigenvectors: A u = lambda u
+    ld = w0.shape[2]
+    u = (w0.cpu().double()[:, :, :n] / sigma.cpu().double().clamp(min=1e-300).unsqueeze(-1))[:, :rank]
+    resid = u @ a - ev[:, :rank].unsqueeze(-1) * u
+    assert float(resid.abs().max()) < 2e-5 * float(ref.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d_in,d_out", [(240, 64, 32), (4096, 384, 192), (1000, 768, 192)])
+def test_token_gram(nat, rows, d_in, d_out, dtype):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, d_in, generator=g).to(dtype)
+    p = torch.linalg.qr(torch.randn(d_in, d_out, generator=g))[0].T.contiguous()
+    gram, colsum = nat.token_gram(x.cuda(), p.cuda())
+    z = x.double() @ p.double().T
+    ref = z.T @ z
+    assert torch.allclose(gram.cpu(), ref, rtol=0, atol=3e-6 * float(ref.abs().max()))
+    assert torch.allclose(colsum.cpu(), z.sum(0), rtol=0, atol=3e-6 * float(z.abs().sum(0).max()))
+    assert torch.allclose(gram, gram.T, rtol=0, atol=1e-12 * float(ref.abs().max()))
+
+
+def test_mp_rank_matches_oracle(nat):
+    from oracle import basd_oracle as O
+    g = torch.Generator().manual_seed(0)
+    mats, want = [], []
+    for r in (3, 9, 0, 31):
+        z = torch.randn(400, 32, generator=g)
+        if r:
+            z = z + 3.0 * (torch.randn(400, r, generator=g) @ torch.randn(r, 32, generator=g)) / r ** 0.5
+        mats.append(torch.linalg.eigvalsh((z.T @ z).double()).float())
+        want.append(min(O.mp_rank(z), 31))
+    ranks = nat.mp_rank(torch.stack(mats).cuda(), 400, 32, 31)
+    assert ranks.tolist() == want
+    # M < D branch of the reference (layer_selector.py:14-15)
+    z = torch.randn(20, 32, generator=g) + 3.0 * torch.randn(20, 2, generator=g) @ torch.randn(2, 32, generator=g)
+    ev = torch.linalg.eigvalsh((z.T @ z).double()).float().unsqueeze(0)
+    assert nat.mp_rank(ev.cuda(), 20, 32, 31).tolist() == [min(O.mp_rank(z), 31)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mix_and_dots(nat, dtype):
+    g = torch.Generator().manual_seed(1)
+    L, E = 5, 4
+    layers = [torch.randn(3, 40, 64, generator=g).to(dtype) for _ in range(L)]
+    w = torch.softmax(torch.randn(E, L, generator=g), dim=1)
+    out = nat.mix_tokens([t.cuda() for t in layers], w.cuda())
+    ref = torch.einsum("el,lbnd->ebnd", w.double(), torch.stack(layers).double())
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-6, atol=1e-6)
+    gr = torch.randn(E, 3, 40, 64, generator=g)
+    dots = nat.mix_grad_dots([t.cuda() for t in layers], gr.cuda())
+    refd = torch.einsum("ebnd,lbnd->el", gr.double(), torch.stack(layers).double())
+    assert torch.allclose(dots.cpu(), refd, rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("n_t", [40, 49, 9])
+def test_procrustes_prep(nat, n_t):
+    from oracle import basd_oracle as O
+    g = torch.Generator().manual_seed(n_t)
+    B, n_s, d_s, d_t = 3, 40, 32, 64
+    s = torch.randn(B, n_s, d_s, generator=g)
+    t = torch.randn(B, n_t, d_t, generator=g)
+    imp = torch.rand(B, n_t, generator=g) + 0.1
+    s_w, t_w, a, tr = nat.procrustes_prep(s.cuda(), t.cuda(), imp.cuda())
+    sd, td, impd = s.double(), O.resample_linear(t.double(), n_s), imp.double()
+    if n_t != n_s:
+        impd = O.resample_linear(impd.unsqueeze(-1), n_s).squeeze(-1)
+    w = impd / impd.sum(-1, keepdim=True)
+    wc = w.unsqueeze(-1)
+    s_ref = wc.sqrt() * (sd - (wc * sd).sum(1, keepdim=True))
+    t_ref = wc.sqrt() * (td - (wc * td).sum(1, keepdim=True))
+    assert torch.allclose(a.cpu().double(), w, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(s_w.cpu().double(), s_ref, atol=2e-6)
+    assert torch.allclose(t_w.cpu().double(), t_ref, atol=2e-6)
+    assert torch.allclose(tr[:, 0].cpu().double(), (s_ref ** 2).sum((1, 2)), rtol=1e-5)
+    assert torch.allclose(tr[:, 1].cpu().double(), (t_ref ** 2).sum((1, 2)), rtol=1e-5)

@@ -1,0 +1,213 @@
+"""ctypes binding of ``libbasd_hip.so`` (C-ABI declared in include/basd_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails this
+module raises.  torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbasd_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+JACOBI_LDS_BYTES = 163840
+
+EXPORTS = (
+    "basd_version", "basd_last_error", "basd_token_gram", "basd_pchol_f64", "basd_jacobi_svd",
+    "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
+)
+
+
+class BasdNativeError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into the in-tree shared library."""
+    res = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise BasdNativeError(f"building libbasd_hip.so failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(res.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BasdNativeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the BASD kernels)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.basd_last_error.restype = ctypes.c_char_p
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise BasdNativeError(f"{LIB_PATH} does not export {name}")
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().basd_last_error().decode()
+        raise BasdNativeError(f"{what} failed with status {rc}: {msg}")
+
+
+def _ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    raise BasdNativeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise BasdNativeError("BASD kernels need tensors on an MI355X device (no CPU path)")
+
+
+def jacobi_ld(m_rows: int) -> int:
+    """Column stride used for LDS-resident Jacobi inputs (multiple of 4, not of 32)."""
+    ld = (m_rows + 3) // 4 * 4
+    if ld % 32 == 0:
+        ld += 4
+    return ld
+
+
+# --------------------------------------------------------------------------- #
+def token_gram(x: torch.Tensor, proj: torch.Tensor):
+    """x [M, d_in] (f32/bf16), proj [d_out, d_in] f32 -> gram [d_out, d_out] f64, colsum [d_out] f64."""
+    _need_cuda(x, proj)
+    x = x.contiguous()
+    proj = proj.contiguous().float()
+    m, d_in = x.shape
+    d_out = proj.shape[0]
+    gram = torch.zeros(d_out, d_out, dtype=torch.float64, device=x.device)
+    colsum = torch.zeros(d_out, dtype=torch.float64, device=x.device)
+    _check(lib().basd_token_gram(_ptr(x), _dtype_code(x), ctypes.c_int64(m), d_in, _ptr(proj), d_out,
+                                 _ptr(gram), _ptr(colsum), _stream()), "basd_token_gram")
+    return gram, colsum
+
+
+def pchol(a: torch.Tensor, tol: float = 1e-13):
+    """a [batch, n, n] f64 PSD -> (w0 [batch, n, ld] f32, lwork [batch, n, n] f64, piv, rank)."""
+    _need_cuda(a)
+    a = a.contiguous()
+    batch, n, _ = a.shape
+    ld = jacobi_ld(n)
+    w0 = torch.empty(batch, n, ld, dtype=torch.float32, device=a.device)
+    lwork = torch.empty(batch, n, n, dtype=torch.float64, device=a.device)
+    piv = torch.empty(batch, n, dtype=torch.int32, device=a.device)
+    rank = torch.empty(batch, dtype=torch.int32, device=a.device)
+    _check(lib().basd_pchol_f64(_ptr(a), batch, n, ctypes.c_double(tol), _ptr(w0), ld, _ptr(lwork),
+                                _ptr(piv), _ptr(rank), _stream()), "basd_pchol_f64")
+    return w0, lwork, piv, rank
+
+
+def jacobi_svd(w: torch.Tensor, m_rows: int, norm_rows: int | None = None, *, tol: float | None = None,
+               max_sweeps: int = 40, sort: bool = True):
+    """In-place one-sided Jacobi on w [batch, n_cols, ld] (column-major matrices).
+
+    Returns (sigma [batch, n_cols], sweeps [batch]); w's columns become sigma_c * u_c.
+    """
+    _need_cuda(w)
+    assert w.is_contiguous() and w.dtype == torch.float32
+    batch, n_cols, ld = w.shape
+    if norm_rows is None:
+        norm_rows = m_rows
+    if tol is None:
+        tol = (m_rows ** 0.5) * 5.96e-8
+    sigma = torch.empty(batch, n_cols, dtype=torch.float32, device=w.device)
+    sweeps = torch.empty(batch, dtype=torch.int32, device=w.device)
+    _check(lib().basd_jacobi_svd(_ptr(w), batch, m_rows, n_cols, ld, norm_rows, ctypes.c_float(tol),
+                                 max_sweeps, int(sort), _ptr(sigma), _ptr(sweeps), _stream()),
+           "basd_jacobi_svd")
+    return sigma, sweeps
+
+
+def jacobi_fits(n_cols: int, m_rows: int) -> bool:
+    return n_cols <= 256 and n_cols * jacobi_ld(m_rows) * 4 + 520 * 4 <= JACOBI_LDS_BYTES
+
+
+def mp_rank(evals: torch.Tensor, rows: int, d: int, cap: int) -> torch.Tensor:
+    """evals [batch, n] (eigenvalues of X^T X) -> int32 ranks [batch], on device."""
+    _need_cuda(evals)
+    evals = evals.contiguous().float()
+    batch, n = evals.shape
+    ranks = torch.empty(batch, dtype=torch.int32, device=evals.device)
+    _check(lib().basd_mp_rank(_ptr(evals), batch, n, ctypes.c_int64(rows), d, cap, _ptr(ranks), _stream()),
+           "basd_mp_rank")
+    return ranks
+
+
+def _ptr_table(layers: list[torch.Tensor]) -> torch.Tensor:
+    return torch.tensor([t.data_ptr() for t in layers], dtype=torch.int64, device=layers[0].device)
+
+
+def mix_tokens(layers: list[torch.Tensor], w: torch.Tensor) -> torch.Tensor:
+    """layers: L tensors of identical shape/dtype; w [E, L] f32 -> out [E, *shape] f32."""
+    _need_cuda(*layers, w)
+    layers = [t.contiguous() for t in layers]
+    code = _dtype_code(layers[0])
+    assert all(t.shape == layers[0].shape and t.dtype == layers[0].dtype for t in layers)
+    E, L = w.shape
+    assert L == len(layers)
+    elems = layers[0].numel()
+    out = torch.empty((E,) + tuple(layers[0].shape), dtype=torch.float32, device=w.device)
+    table = _ptr_table(layers)
+    _check(lib().basd_mix_tokens(_ptr(table), code, L, E, _ptr(w.contiguous().float()),
+                                 ctypes.c_int64(elems), _ptr(out), _stream()), "basd_mix_tokens")
+    return out
+
+
+def mix_grad_dots(layers: list[torch.Tensor], g: torch.Tensor) -> torch.Tensor:
+    """dots[i, j] = <g[i], layers[j]>; g [E, *shape] f32 -> [E, L] f64."""
+    _need_cuda(*layers, g)
+    layers = [t.contiguous() for t in layers]
+    code = _dtype_code(layers[0])
+    E, L = g.shape[0], len(layers)
+    elems = layers[0].numel()
+    assert g.numel() == E * elems and g.dtype == torch.float32
+    dots = torch.zeros(E, L, dtype=torch.float64, device=g.device)
+    table = _ptr_table(layers)
+    _check(lib().basd_mix_grad_dots(_ptr(table), code, L, E, _ptr(g.contiguous()), ctypes.c_int64(elems),
+                                    _ptr(dots), _stream()), "basd_mix_grad_dots")
+    return dots
+
+
+def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor):
+    """s [B,N_s,D_s] (f32/bf16), t [B,N_t,D_t] f32, imp [B,N_t] f32 -> s_w, t_w, a, tr[B,2]."""
+    _need_cuda(s, t, imp)
+    s = s.contiguous()
+    t = t.contiguous().float()
+    imp = imp.contiguous().float()
+    B, N_s, D_s = s.shape
+    _, N_t, D_t = t.shape
+    dev = s.device
+    s_w = torch.empty(B, N_s, D_s, dtype=torch.float32, device=dev)
+    t_w = torch.empty(B, N_s, D_t, dtype=torch.float32, device=dev)
+    a = torch.empty(B, N_s, dtype=torch.float32, device=dev)
+    tr = torch.empty(B, 2, dtype=torch.float32, device=dev)
+    _check(lib().basd_procrustes_prep(_ptr(s), _dtype_code(s), _ptr(t), _ptr(imp), B, N_s, N_t, D_s, D_t,
+                                      _ptr(s_w), _ptr(t_w), _ptr(a), _ptr(tr), _stream()),
+           "basd_procrustes_prep")
+    return s_w, t_w, a, tr

@@ -1,0 +1,359 @@
+// HBM-streaming kernels of the BASD loss path:
+//   mix_tokens        all E softmax-weighted mixes of the L teacher layers from ONE read of
+//                     each layer (reference src/losses/layer_selector.py:110-112 re-reads the
+//                     [L,B,N,D] stack E times and materialises a same-size temporary)
+//   mix_grad_dots     d loss / d w[i,j] = <g_i, x_j> for all (i,j) from one read of each layer
+//   procrustes_prep   resample + importance normalise + weighted centring + sqrt-weighting
+//                     (src/losses/relational.py:29-46, src/losses/combined.py:9-14)
+// Loads are 16 B per lane (8 bf16 / 4 fp32), grid-stride, <= 2048 workgroups.
+#include "basd_common.h"
+
+namespace basd {
+
+constexpr int kMaxE = 8;
+constexpr int kMaxL = 64;
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+template <> struct Vec<unsigned short> {   // bf16 bits
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned int w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+};
+
+template <typename T, int E>
+__global__ __launch_bounds__(256) void mix_tokens_kernel(const T* const* __restrict__ layers, int L,
+                                                         const float* __restrict__ w, int64_t nvec,
+                                                         float* __restrict__ out, int64_t elems) {
+  constexpr int N = Vec<T>::N;
+  __shared__ float s_w[kMaxE * kMaxL];
+  __shared__ const T* s_ptr[kMaxL];
+  for (int i = threadIdx.x; i < E * L; i += blockDim.x) s_w[i] = w[i];
+  for (int i = threadIdx.x; i < L; i += blockDim.x) s_ptr[i] = layers[i];
+  __syncthreads();
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+       v += (int64_t)gridDim.x * blockDim.x) {
+    float acc[E][N];
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[i][k] = 0.f;
+    for (int j = 0; j < L; ++j) {
+      float x[N];
+      Vec<T>::load(s_ptr[j] + v * N, x);
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float wij = s_w[i * L + j];
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[i][k] = fmaf(wij, x[k], acc[i][k]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      float* o = out + (int64_t)i * elems + v * N;
+#pragma unroll
+      for (int k = 0; k < N; k += 4)
+        *reinterpret_cast<float4*>(o + k) = make_float4(acc[i][k], acc[i][k + 1], acc[i][k + 2], acc[i][k + 3]);
+    }
+  }
+}
+
+template <typename T, int E>
+__global__ __launch_bounds__(256) void mix_grad_dots_kernel(const T* const* __restrict__ layers, int L,
+                                                            const float* __restrict__ g, int64_t nvec,
+                                                            int64_t elems, double* __restrict__ dots) {
+  constexpr int N = Vec<T>::N;
+  __shared__ const T* s_ptr[kMaxL];
+  __shared__ double s_acc[kMaxE * kMaxL];
+  for (int i = threadIdx.x; i < L; i += blockDim.x) s_ptr[i] = layers[i];
+  for (int i = threadIdx.x; i < E * L; i += blockDim.x) s_acc[i] = 0.0;
+  __syncthreads();
+  // per-thread fp32 partials over a bounded number of vectors, then fp64
+  for (int j0 = 0; j0 < L; j0 += 16) {
+    const int jn = (L - j0) < 16 ? (L - j0) : 16;
+    float acc[E][16];
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+         v += (int64_t)gridDim.x * blockDim.x) {
+      float gv[E][N];
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float* gp = g + (int64_t)i * elems + v * N;
+#pragma unroll
+        for (int k = 0; k < N; k += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(gp + k);
+          gv[i][k] = t.x; gv[i][k + 1] = t.y; gv[i][k + 2] = t.z; gv[i][k + 3] = t.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < jn) {
+          float x[N];
+          Vec<T>::load(s_ptr[j0 + j] + v * N, x);
+#pragma unroll
+          for (int i = 0; i < E; ++i) {
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < N; ++k) d = fmaf(gv[i][k], x[k], d);
+            acc[i][j] += d;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < jn) {
+          const double s = wave_sum_d((double)acc[i][j]);
+          if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[i * L + j0 + j], s);
+        }
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < E * L; i += blockDim.x) atomicAdd(&dots[i], s_acc[i]);
+}
+
+// one workgroup per sample
+template <typename TS>
+__global__ __launch_bounds__(512) void procrustes_prep_kernel(
+    const TS* __restrict__ s_all, const float* __restrict__ t_all, const float* __restrict__ imp_all,
+    int N_s, int N_t, int D_s, int D_t, float* __restrict__ sw_all, float* __restrict__ tw_all,
+    float* __restrict__ a_all, float* __restrict__ tr_all) {
+  extern __shared__ __align__(16) float sm[];
+  float* s_a = sm;                 // [N_s] normalised importance
+  int* s_lo = reinterpret_cast<int*>(s_a + N_s);   // [N_s]
+  float* s_fr = reinterpret_cast<float*>(s_lo + N_s);  // [N_s]
+  float* s_mu = s_fr + N_s;        // [D_s + D_t]
+  float* s_red = s_mu + D_s + D_t; // [32]
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const TS* s = s_all + (size_t)b * N_s * D_s;
+  const float* t = t_all + (size_t)b * N_t * D_t;
+  const float* imp = imp_all + (size_t)b * N_t;
+  float* sw = sw_all + (size_t)b * N_s * D_s;
+  float* tw = tw_all + (size_t)b * N_s * D_t;
+
+  // resample taps (F.interpolate linear, align_corners=False) and importance
+  const float ratio = (float)N_t / (float)N_s;
+  float part = 0.f;
+  for (int n = tid; n < N_s; n += nt) {
+    float pos = ((float)n + 0.5f) * ratio - 0.5f;
+    pos = pos < 0.f ? 0.f : pos;
+    int lo = (int)pos;
+    if (lo > N_t - 1) lo = N_t - 1;
+    const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+    const float fr = (N_t == N_s) ? 0.f : pos - (float)lo;
+    const float v = (N_t == N_s) ? imp[n] : imp[lo] * (1.f - fr) + imp[hi] * fr;
+    s_a[n] = v; s_lo[n] = lo; s_fr[n] = fr;
+    part += v;
+  }
+  part = wave_sum(part);
+  if ((tid & 63) == 0) s_red[tid >> 6] = part;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < (nt >> 6); ++w) tot += s_red[w];
+  __syncthreads();
+  for (int n = tid; n < N_s; n += nt) {
+    const float an = s_a[n] / tot;
+    s_a[n] = an;
+    a_all[(size_t)b * N_s + n] = an;
+  }
+  __syncthreads();
+  // weighted means: one thread per feature column (coalesced along d)
+  for (int d = tid; d < D_s + D_t; d += nt) {
+    float mu = 0.f;
+    if (d < D_s) {
+      for (int n = 0; n < N_s; ++n) {
+        float x;
+        if constexpr (sizeof(TS) == 2) x = bf16_bits_to_f32(s[(size_t)n * D_s + d]);
+        else x = s[(size_t)n * D_s + d];
+        mu = fmaf(s_a[n], x, mu);
+      }
+    } else {
+      const int dd = d - D_s;
+      for (int n = 0; n < N_s; ++n) {
+        const int lo = s_lo[n];
+        const float fr = s_fr[n];
+        float x = t[(size_t)lo * D_t + dd];
+        if (fr != 0.f) {
+          const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+          x = x * (1.f - fr) + t[(size_t)hi * D_t + dd] * fr;
+        }
+        mu = fmaf(s_a[n], x, mu);
+      }
+    }
+    s_mu[d] = mu;
+  }
+  __syncthreads();
+  double trs = 0.0, trt = 0.0;
+  for (int d = tid; d < D_s + D_t; d += nt) {
+    const float mu = s_mu[d];
+    if (d < D_s) {
+      for (int n = 0; n < N_s; ++n) {
+        float x;
+        if constexpr (sizeof(TS) == 2) x = bf16_bits_to_f32(s[(size_t)n * D_s + d]);
+        else x = s[(size_t)n * D_s + d];
+        const float v = sqrtf(s_a[n]) * (x - mu);
+        sw[(size_t)n * D_s + d] = v;
+        trs += (double)v * (double)v;
+      }
+    } else {
+      const int dd = d - D_s;
+      for (int n = 0; n < N_s; ++n) {
+        const int lo = s_lo[n];
+        const float fr = s_fr[n];
+        float x = t[(size_t)lo * D_t + dd];
+        if (fr != 0.f) {
+          const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+          x = x * (1.f - fr) + t[(size_t)hi * D_t + dd] * fr;
+        }
+        const float v = sqrtf(s_a[n]) * (x - mu);
+        tw[(size_t)n * D_t + dd] = v;
+        trt += (double)v * (double)v;
+      }
+    }
+  }
+  trs = wave_sum_d(trs); trt = wave_sum_d(trt);
+  if ((tid & 63) == 0) { s_red[tid >> 6] = (float)trs; s_red[16 + (tid >> 6)] = (float)trt; }
+  __syncthreads();
+  if (tid == 0) {
+    float x = 0.f, y = 0.f;
+    for (int w = 0; w < (nt >> 6); ++w) { x += s_red[w]; y += s_red[16 + w]; }
+    tr_all[(size_t)b * 2] = x; tr_all[(size_t)b * 2 + 1] = y;
+  }
+}
+
+static int grid_for(int64_t nvec) {
+  int64_t g = (nvec + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace basd
+
+namespace basd {
+
+template <typename T, int E>
+static void launch_mix(const void* const* layers, int L, const float* w, int64_t nvec, float* out,
+                       int64_t elems, hipStream_t st) {
+  hipLaunchKernelGGL((mix_tokens_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st,
+                     (const T* const*)layers, L, w, nvec, out, elems);
+}
+template <typename T, int E>
+static void launch_dots(const void* const* layers, int L, const float* g, int64_t nvec, int64_t elems,
+                        double* dots, hipStream_t st) {
+  hipLaunchKernelGGL((mix_grad_dots_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st,
+                     (const T* const*)layers, L, g, nvec, elems, dots);
+}
+
+template <typename T>
+static int dispatch_mix(int E, const void* const* layers, int L, const float* w, int64_t nvec, float* out,
+                        int64_t elems, hipStream_t st) {
+  switch (E) {
+    case 1: launch_mix<T, 1>(layers, L, w, nvec, out, elems, st); break;
+    case 2: launch_mix<T, 2>(layers, L, w, nvec, out, elems, st); break;
+    case 3: launch_mix<T, 3>(layers, L, w, nvec, out, elems, st); break;
+    case 4: launch_mix<T, 4>(layers, L, w, nvec, out, elems, st); break;
+    case 5: launch_mix<T, 5>(layers, L, w, nvec, out, elems, st); break;
+    case 6: launch_mix<T, 6>(layers, L, w, nvec, out, elems, st); break;
+    case 7: launch_mix<T, 7>(layers, L, w, nvec, out, elems, st); break;
+    case 8: launch_mix<T, 8>(layers, L, w, nvec, out, elems, st); break;
+    default: return fail(BASD_ERR_SHAPE, "E=%d out of 1..8", E);
+  }
+  return BASD_OK;
+}
+template <typename T>
+static int dispatch_dots(int E, const void* const* layers, int L, const float* g, int64_t nvec,
+                         int64_t elems, double* dots, hipStream_t st) {
+  switch (E) {
+    case 1: launch_dots<T, 1>(layers, L, g, nvec, elems, dots, st); break;
+    case 2: launch_dots<T, 2>(layers, L, g, nvec, elems, dots, st); break;
+    case 3: launch_dots<T, 3>(layers, L, g, nvec, elems, dots, st); break;
+    case 4: launch_dots<T, 4>(layers, L, g, nvec, elems, dots, st); break;
+    case 5: launch_dots<T, 5>(layers, L, g, nvec, elems, dots, st); break;
+    case 6: launch_dots<T, 6>(layers, L, g, nvec, elems, dots, st); break;
+    case 7: launch_dots<T, 7>(layers, L, g, nvec, elems, dots, st); break;
+    case 8: launch_dots<T, 8>(layers, L, g, nvec, elems, dots, st); break;
+    default: return fail(BASD_ERR_SHAPE, "E=%d out of 1..8", E);
+  }
+  return BASD_OK;
+}
+
+}  // namespace basd
+
+extern "C" int basd_mix_tokens(const void* const* x_layers, int x_dtype, int L, int E, const float* w,
+                               int64_t elems, float* out, void* stream) {
+  using namespace basd;
+  if (L < 1 || L > kMaxL) return fail(BASD_ERR_SHAPE, "mix_tokens: L=%d out of 1..%d", L, kMaxL);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (x_dtype == BASD_DTYPE_F32) {
+    if (elems % 4) return fail(BASD_ERR_SHAPE, "mix_tokens: elems %% 4 != 0");
+    rc = dispatch_mix<float>(E, x_layers, L, w, elems / 4, out, elems, st);
+  } else if (x_dtype == BASD_DTYPE_BF16) {
+    if (elems % 8) return fail(BASD_ERR_SHAPE, "mix_tokens: elems %% 8 != 0");
+    rc = dispatch_mix<unsigned short>(E, x_layers, L, w, elems / 8, out, elems, st);
+  } else {
+    return fail(BASD_ERR_DTYPE, "mix_tokens: dtype %d", x_dtype);
+  }
+  if (rc) return rc;
+  return check_launch("mix_tokens");
+}
+
+extern "C" int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int L, int E, const float* g,
+                                  int64_t elems, double* dots, void* stream) {
+  using namespace basd;
+  if (L < 1 || L > kMaxL) return fail(BASD_ERR_SHAPE, "mix_grad_dots: L=%d out of 1..%d", L, kMaxL);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (x_dtype == BASD_DTYPE_F32) {
+    if (elems % 4) return fail(BASD_ERR_SHAPE, "mix_grad_dots: elems %% 4 != 0");
+    rc = dispatch_dots<float>(E, x_layers, L, g, elems / 4, elems, dots, st);
+  } else if (x_dtype == BASD_DTYPE_BF16) {
+    if (elems % 8) return fail(BASD_ERR_SHAPE, "mix_grad_dots: elems %% 8 != 0");
+    rc = dispatch_dots<unsigned short>(E, x_layers, L, g, elems / 8, elems, dots, st);
+  } else {
+    return fail(BASD_ERR_DTYPE, "mix_grad_dots: dtype %d", x_dtype);
+  }
+  if (rc) return rc;
+  return check_launch("mix_grad_dots");
+}
+
+extern "C" int basd_procrustes_prep(const void* s, int s_dtype, const float* t, const float* imp, int B,
+                                    int N_s, int N_t, int D_s, int D_t, float* s_w, float* t_w,
+                                    float* a, float* tr, void* stream) {
+  using namespace basd;
+  if (B <= 0) return BASD_OK;
+  if (N_s < 1 || N_t < 1 || D_s < 1 || D_t < 1)
+    return fail(BASD_ERR_SHAPE, "procrustes_prep: bad shape");
+  const size_t lds = (size_t)(3 * N_s + D_s + D_t + 32) * 4;
+  if (lds > 160 * 1024) return fail(BASD_ERR_SHAPE, "procrustes_prep: LDS %zu too large", lds);
+  hipStream_t st = (hipStream_t)stream;
+  if (s_dtype == BASD_DTYPE_F32) {
+    hipLaunchKernelGGL(procrustes_prep_kernel<float>, dim3(B), dim3(512), lds, st, (const float*)s, t, imp,
+                       N_s, N_t, D_s, D_t, s_w, t_w, a, tr);
+  } else if (s_dtype == BASD_DTYPE_BF16) {
+    hipLaunchKernelGGL(procrustes_prep_kernel<unsigned short>, dim3(B), dim3(512), lds, st,
+                       (const unsigned short*)s, t, imp, N_s, N_t, D_s, D_t, s_w, t_w, a, tr);
+  } else {
+    return fail(BASD_ERR_DTYPE, "procrustes_prep: dtype %d", s_dtype);
+  }
+  return check_launch("procrustes_prep");
+}
