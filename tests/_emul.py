@@ -1,0 +1,123 @@
+"""TEST-ONLY torch/CPU emulation of the C-ABI kernels (same call surface as
+``basd_amd._native``).  It lets the CPU suite check the host logic -- autograd
+formulas, masking, module plumbing -- against the golden vectors.  It is never
+imported by the package; the product path is the HIP library only."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+JACOBI_LDS_BYTES = 163840
+
+
+def jacobi_ld(m_rows: int) -> int:
+    ld = (m_rows + 3) // 4 * 4
+    if ld % 32 == 0:
+        ld += 4
+    return ld
+
+
+def jacobi_fits(n_cols: int, m_rows: int) -> bool:
+    return n_cols <= 256 and n_cols * jacobi_ld(m_rows) * 4 + 520 * 4 <= JACOBI_LDS_BYTES
+
+
+def token_gram(x, proj):
+    z = (x.float() @ proj.float().t()).double()
+    return z.t() @ z, z.sum(0)
+
+
+def pchol(a, tol=1e-13):
+    a = a.double()
+    batch, n, _ = a.shape
+    ld = jacobi_ld(n)
+    lwork = torch.zeros(batch, n, n, dtype=torch.float64)
+    piv = torch.zeros(batch, n, dtype=torch.int32)
+    rank = torch.zeros(batch, dtype=torch.int32)
+    for b in range(batch):
+        d = torch.diagonal(a[b]).clone()
+        alive = torch.ones(n, dtype=torch.bool)
+        dmax0 = float(d.max())
+        k = 0
+        order = []
+        while k < n:
+            cand = torch.where(alive, d, torch.full_like(d, -1e300))
+            p = int(cand.argmax())
+            if not (float(cand[p]) > tol * dmax0) or not (float(cand[p]) > 0):
+                break
+            v = a[b, p] - lwork[b, :k].t() @ lwork[b, :k, p]
+            v = torch.where(alive, v, torch.zeros_like(v))
+            lkk = math.sqrt(max(float(v[p]), 0.0))
+            col = v / lkk
+            col[p] = lkk
+            lwork[b, k] = col
+            d = d - col * col
+            alive[p] = False
+            order.append(p)
+            k += 1
+        rank[b] = k
+        order += [i for i in range(n) if alive[i]]
+        piv[b] = torch.tensor(order, dtype=torch.int32)
+    w0 = torch.zeros(batch, n, ld, dtype=torch.float32)
+    w0[:, :, :n] = lwork.float()
+    return w0, lwork, piv, rank
+
+
+def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True):
+    batch, n_cols, ld = w.shape
+    if norm_rows is None:
+        norm_rows = m_rows
+    sigma = torch.zeros(batch, n_cols, dtype=torch.float32)
+    for b in range(batch):
+        full = w[b, :, :m_rows].double().t()           # [m, n]
+        top = full[:norm_rows]
+        u, s, vh = torch.linalg.svd(top, full_matrices=False)
+        r = s.shape[0]
+        out = torch.zeros(m_rows, n_cols, dtype=torch.float64)
+        small = s < 1e-13 * max(float(s[0]), 1e-300)
+        s = torch.where(small, torch.zeros_like(s), s)
+        out[:norm_rows, :r] = u * s
+        if m_rows > norm_rows:                          # stacked [A; B]: B V
+            out[norm_rows:, :r] = full[norm_rows:] @ vh.t()
+        w[b, :, :m_rows] = out.t().float()
+        sigma[b, :r] = s.float()
+    return sigma, torch.full((batch,), 1, dtype=torch.int32)
+
+
+def mp_rank(evals, rows, d, cap):
+    out = []
+    for e in evals:
+        lam = (e.double() / rows)
+        srt, _ = torch.sort(lam, descending=True)
+        n_eff = min(rows, lam.numel())
+        srt = srt[:n_eff]
+        asc = srt.flip(0)
+        sigma2 = asc[(n_eff - 1) // 2]
+        edge = float(sigma2.float()) * (1.0 + math.sqrt(d / rows)) ** 2
+        out.append(min(int((srt.float() > edge).sum()), cap))
+    return torch.tensor(out, dtype=torch.int32)
+
+
+def mix_tokens(layers, w):
+    st = torch.stack([t.float() for t in layers])
+    return torch.einsum("el,l...->e...", w.float(), st).contiguous()
+
+
+def mix_grad_dots(layers, g):
+    st = torch.stack([t.double() for t in layers])
+    return torch.einsum("e...,l...->el", g.double(), st)
+
+
+def procrustes_prep(s, t, imp):
+    from oracle.basd_oracle import resample_linear
+    s, t, imp = s.float(), t.float(), imp.float()
+    n_s = s.shape[1]
+    t = resample_linear(t, n_s)
+    if imp.shape[1] != n_s:
+        imp = resample_linear(imp.unsqueeze(-1), n_s).squeeze(-1)
+    a = imp / imp.sum(-1, keepdim=True)
+    wc = a.unsqueeze(-1)
+    s_w = wc.sqrt() * (s - (wc * s).sum(1, keepdim=True))
+    t_w = wc.sqrt() * (t - (wc * t).sum(1, keepdim=True))
+    tr = torch.stack([(s_w.double() ** 2).sum((1, 2)), (t_w.double() ** 2).sum((1, 2))], dim=1).float()
+    return s_w.contiguous(), t_w.contiguous(), a, tr

@@ -1,0 +1,52 @@
+"""Host logic of basd_amd.losses (autograd formulas, rank masking, module surface)
+checked on CPU against the reference goldens, with the kernels replaced by the
+test-only emulation ``tests/_emul.py``.  The real kernels are checked by the
+``-m gpu`` tests; the product never takes this path."""
+import pytest
+import torch
+
+from tests import _emul
+from tests._golden import load
+from tests._run_loss import check_against_golden, run_basd_loss
+
+
+@pytest.fixture(autouse=True)
+def _emulated_kernels():
+    from basd_amd.losses import _ops
+    _ops.set_ops(_emul)
+    yield
+    _ops.set_ops(None)
+
+
+@pytest.mark.parametrize("kind", ["hard", "soft"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_interp", "tiny_nocls", "tiny_cnn"])
+def test_basd_loss_matches_reference(name, kind):
+    shape, inputs, gold = load(name)
+    res = run_basd_loss(shape, inputs, gold, kind)
+    check_against_golden(gold, res, kind, inputs["token_layers"], grad_tol=2e-4, has_temp_grad=shape.L_t > 1)
+
+
+def test_flat_tail_fixture_within_reference_noise_floor():
+    shape, inputs, gold = load("tiny_flat")
+    res = run_basd_loss(shape, inputs, gold, "hard")
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-3)
+
+
+def test_rank_deficient_values():
+    shape, inputs, gold = load("tiny_rankdef")
+    res = run_basd_loss(shape, inputs, gold, "hard")
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=1.0, check_grads=False)
+
+
+def test_state_dict_keys_match_reference_surface():
+    import types
+    from basd_amd.losses import BASDLoss
+    mod = BASDLoss(torch.nn.CrossEntropyLoss(), 32, 64, 12, 40,
+                   config=types.SimpleNamespace(num_extraction_points=4), teacher_has_cls_token=True)
+    assert sorted(mod.state_dict()) == ["layer_selector.log_temperatures", "layer_selector.proj_s",
+                                        "layer_selector.proj_t"]
+    assert [n for n, _ in mod.named_parameters()] == ["layer_selector.log_temperatures"]
+    assert mod.token_layers == [0, 4, 7, 11]
+    assert float(mod.layer_selector.temperatures[0]) == pytest.approx(1.0)
+    p = mod.layer_selector.proj_t
+    torch.testing.assert_close(p @ p.t(), torch.eye(32), atol=1e-5, rtol=0)

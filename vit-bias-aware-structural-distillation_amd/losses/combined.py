@@ -1,0 +1,71 @@
+"""BASD loss: CE + mean Procrustes over the extraction points, UW-SO weighted.
+
+Mirrors reference ``src/losses/combined.py`` (``_align_token_count`` :9-14,
+``BASDLoss`` :17-85): same constructor and ``forward`` signature, same
+``token_layers`` rule, ``layer_selector`` sub-module and state_dict keys.
+``all_teacher_attns`` may hold full maps ``[B,H,T,T]`` (reference contract) or
+per-layer importance vectors ``[B,N_t]`` (what ``models.teacher`` emits).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as BF
+from .layer_selector import GrassmannianLayerSelector
+
+
+def _align_token_count(tokens: torch.Tensor, target_n: int) -> torch.Tensor:
+    """Linear resample along the token axis (reference combined.py:9-14).
+
+    The fused Procrustes prep does this on the fly; the function is kept for callers
+    of the reference surface.
+    """
+    if tokens.shape[1] == target_n:
+        return tokens
+    r = BF.resample_matrix(tokens.shape[1], target_n, tokens.device, tokens.dtype)
+    return torch.matmul(r, tokens)
+
+
+class BASDLoss(nn.Module):
+    def __init__(self, base_criterion: nn.Module, student_dim: int, teacher_dim: int,
+                 student_depth: int, num_student_tokens: int, *, config, teacher_has_cls_token: bool):
+        super().__init__()
+        self.base_criterion = base_criterion
+        self.teacher_has_cls_token = teacher_has_cls_token
+        self.num_student_tokens = num_student_tokens
+        n_pts = config.num_extraction_points
+        if n_pts == 1:
+            self.token_layers = [student_depth - 1]
+        else:
+            self.token_layers = [round(i * (student_depth - 1) / (n_pts - 1)) for i in range(n_pts)]
+        self.layer_selector = GrassmannianLayerSelector(
+            num_extraction_points=len(self.token_layers), student_dim=student_dim, teacher_dim=teacher_dim)
+        self.last_terms: dict[str, torch.Tensor] = {}
+
+    def forward(self, student_output, targets, student_intermediates, all_teacher_tokens, all_teacher_attns):
+        ce_loss = self.base_criterion(student_output, targets)
+
+        sel = self.layer_selector
+        weights, teacher_indices = sel.mixing_weights(student_intermediates, all_teacher_tokens, self.token_layers)
+        mixed = BF.mix_layers(weights, [all_teacher_tokens[j] for j in teacher_indices])
+        imp = torch.stack([BF.importance_from_attention(all_teacher_attns[j], self.teacher_has_cls_token)
+                           for j in teacher_indices])
+        mixed_imp = torch.einsum("el,lbn->ebn", weights, imp)
+
+        geo_losses = []
+        for i, layer_idx in enumerate(self.token_layers):
+            s = student_intermediates[layer_idx]
+            if s.shape[1] != self.num_student_tokens:
+                raise ValueError(f"student layer {layer_idx} has {s.shape[1]} tokens, expected {self.num_student_tokens}")
+            geo_losses.append(BF.procrustes(s, mixed[i], mixed_imp[i]).mean())
+        geo_each = torch.stack(geo_losses)
+        geo_loss = geo_each.mean()
+
+        # UW-SO (reference combined.py:78-85): w_i = (1/L_i) / sum_j (1/L_j), detached
+        eps = torch.finfo(ce_loss.dtype).eps
+        inv = torch.stack([1.0 / ce_loss.detach().clamp(min=eps), 1.0 / geo_loss.detach().float().clamp(min=eps)])
+        w = inv / inv.sum()
+        self.last_terms = {"ce": ce_loss.detach(), "geo": geo_each.detach()}
+        return w[0] * ce_loss + w[1] * geo_loss

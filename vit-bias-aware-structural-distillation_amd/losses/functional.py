@@ -1,0 +1,283 @@
+"""Autograd functions of the BASD loss path on top of the HIP kernels.
+
+Three differentiable pieces, each a ``torch.autograd.Function`` whose forward
+and backward call the C-ABI kernels (through ``_ops.get_ops()``) plus small
+dense ``torch.bmm`` / triangular-solve calls (plain library GEMMs):
+
+``selector_weights``   per-layer Gram statistics -> MP ranks (on device, no
+                       ``.item()``) -> PCA frames -> masked principal angles
+                       -> softmax mixing weights [E, L]
+                       (reference src/losses/layer_selector.py:69-108, 133-138)
+``mix_layers``         all E weighted mixes of the teacher layers in one pass
+                       (layer_selector.py:110-112)
+``procrustes``         attention-weighted Procrustes value per sample
+                       (src/losses/relational.py:29-50)
+
+Numerical design: every Gram matrix is accumulated in
+fp64, factored by a pivoted fp64 Cholesky (a column-graded factor) and the
+factor is diagonalised by an fp32 one-sided Jacobi in LDS; singular-vector
+pairs that have to be consistent (principal angles, polar factor) are never
+recovered through a division by a small singular value of an un-graded matrix.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from ._ops import get_ops
+
+_EPS32 = float(torch.finfo(torch.float32).eps)
+PCHOL_TOL = 1e-13
+
+
+class BasdShapeError(NotImplementedError):
+    pass
+
+
+# --------------------------------------------------------------------------- #
+# helpers
+# --------------------------------------------------------------------------- #
+def psd_eig(a64: torch.Tensor):
+    """Batched eigen-decomposition of symmetric PSD fp64 matrices [b, n, n].
+
+    Returns (sigma [b, n] fp32 descending = sqrt(eigenvalues), u [b, n, n] fp32 with
+    ROW i the unit eigenvector i (zero rows beyond the numerical rank), aux).
+    """
+    ops = get_ops()
+    n = a64.shape[-1]
+    if not ops.jacobi_fits(n, n):
+        raise BasdShapeError(
+            f"{n}x{n} eigenproblem does not fit the 160 KiB LDS-resident Jacobi (n <= ~200); "
+            "student widths above 192 are out of scope this round (DESIGN.md)")
+    a64 = 0.5 * (a64 + a64.transpose(-1, -2))
+    w0, lwork, piv, rank = ops.pchol(a64, PCHOL_TOL)
+    sigma, _ = ops.jacobi_svd(w0, n)
+    safe = sigma.clamp_min(1e-30).unsqueeze(-1)
+    u = torch.where(sigma.unsqueeze(-1) > 0, w0[:, :, :n] / safe, torch.zeros_like(w0[:, :, :n]))
+    return sigma, u, (w0, lwork, piv, rank)
+
+
+def resample_matrix(n_in: int, n_out: int, device, dtype=torch.float32) -> torch.Tensor:
+    """[n_out, n_in] matrix of F.interpolate(mode='linear', align_corners=False)."""
+    pos = (torch.arange(n_out, device=device, dtype=torch.float64) + 0.5) * (n_in / n_out) - 0.5
+    pos = pos.clamp(min=0.0)
+    lo = pos.floor().long().clamp(max=n_in - 1)
+    hi = (lo + 1).clamp(max=n_in - 1)
+    fr = (pos - lo.double())
+    r = torch.zeros(n_out, n_in, device=device, dtype=torch.float64)
+    rows = torch.arange(n_out, device=device)
+    r.index_put_((rows, lo), 1.0 - fr, accumulate=True)
+    r.index_put_((rows, hi), fr, accumulate=True)
+    return r.to(dtype)
+
+
+def importance_from_attention(attn: torch.Tensor, has_cls_token: bool) -> torch.Tensor:
+    """[B,H,T,T] (or compact [B,H,1,T]) attention -> [B,N] importance, relational.py:22-27."""
+    if attn.dim() == 2:
+        return attn.float()
+    if has_cls_token:
+        return attn[:, :, 0, 1:].float().mean(dim=1)
+    return attn.float().mean(dim=(1, 2))
+
+
+# --------------------------------------------------------------------------- #
+# selector weights
+# --------------------------------------------------------------------------- #
+class _SelectorWeightsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_temp, proj_s, proj_t, n_student, *tokens):
+        ops = get_ops()
+        student = tokens[:n_student]
+        teacher = tokens[n_student:]
+        E, L = len(student), len(teacher)
+        D = proj_s.shape[0]
+        dev = proj_s.device
+
+        mats = []
+        m_t = teacher[0].shape[0] * teacher[0].shape[1]
+        cen_t = []
+        for x in teacher:                               # layer_selector.py:71-73, :134-136
+            g, c = ops.token_gram(x.reshape(-1, x.shape[-1]), proj_t)
+            mats.append(g)
+            cen_t.append(g - torch.outer(c, c) / m_t)
+        mats.extend(cen_t)
+        m_s = student[0].shape[0] * student[0].shape[1]
+        for s in student:                               # layer_selector.py:84-92
+            g, c = ops.token_gram(s.reshape(-1, s.shape[-1]), proj_s)
+            mats.append(g - torch.outer(c, c) / m_s)
+        sigma, u, _ = psd_eig(torch.stack(mats))
+        ranks = ops.mp_rank(sigma[:L] ** 2, m_t, D, D - 1)          # int32 [L], stays on device
+        v_t, s_t = u[L:2 * L], sigma[L:2 * L]
+        v_s, lam_s = u[2 * L:], sigma[2 * L:].double() ** 2
+
+        idx = torch.arange(D, device=dev)
+        keep = (idx.unsqueeze(0) < ranks.unsqueeze(1)).float()      # [L, D]  (index < k_j)
+        vm_t = v_t * keep.unsqueeze(-1)
+        sw = s_t * keep
+        a_full = torch.einsum("ibd,jcd->ijbc", v_s, vm_t)           # [E, L, D(b), D(c)]
+        a_bar = a_full * keep.view(1, L, D, 1)                      # rows b < k_j
+
+        ld = ops.jacobi_ld(D)
+        w = torch.zeros(E * L, D, ld, device=dev, dtype=torch.float32)
+        w[:, :, :D] = a_bar.reshape(E * L, D, D).transpose(1, 2)    # column c contiguous
+        sig, _ = ops.jacobi_svd(w, D)                               # cosines, descending
+        sig = sig.view(E, L, D)
+        u_s = torch.where(sig.unsqueeze(-1) > 1e-20, w[:, :, :D].view(E, L, D, D) / sig.clamp_min(1e-20).unsqueeze(-1),
+                          torch.zeros(1, device=dev))               # [E, L, m, b]
+        sig_c = sig.clamp(max=1.0 - _EPS32)                         # layer_selector.py:100
+        theta = torch.acos(sig_c)
+        den = sw.sum(-1)                                            # [L]; 0 at rank 0 -> NaN like the reference
+        d2 = (sw.unsqueeze(0) * theta * theta).sum(-1) / den.unsqueeze(0)   # [E, L]
+        tau = F.softplus(log_temp.float())
+        pre = -d2 / tau.unsqueeze(1)
+        wts = torch.softmax(pre, dim=1)
+
+        # seeds of the backward, per unit d(d2_ij): Phi = U diag(gsig / sig) U^T, T = A_full A_bar^T Phi
+        gsig = sw.unsqueeze(0) * 2.0 * theta * (-1.0 / torch.sqrt(1.0 - sig_c * sig_c)) / den.view(1, L, 1)
+        gsig = torch.where(sig <= 1.0 - _EPS32, gsig, torch.zeros_like(gsig))
+        ratio = torch.where(sig > 1e-12, gsig / sig.clamp_min(1e-12), torch.zeros_like(gsig))
+        phi = torch.einsum("ijmb,ijm,ijmc->ijbc", u_s, ratio, u_s)
+        t_seed = a_full @ a_bar.transpose(-1, -2) @ phi              # [E, L, D(b), D(a)]
+        t_seed = t_seed * (1.0 - keep).view(1, L, D, 1)              # only b >= k_j (cross-subspace terms)
+
+        ctx.save_for_backward(log_temp, proj_s, wts, d2, tau, t_seed, v_s, lam_s, *student)
+        ctx.n_student = E
+        ctx.mark_non_differentiable(ranks)
+        return wts, ranks, pre
+
+    @staticmethod
+    def backward(ctx, g_w, _g_ranks, g_pre_out):
+        log_temp, proj_s, wts, d2, tau, t_seed, v_s, lam_s, *student = ctx.saved_tensors
+        E = ctx.n_student
+        g_pre = wts * (g_w - (wts * g_w).sum(dim=1, keepdim=True))
+        if g_pre_out is not None:
+            g_pre = g_pre + g_pre_out
+        g_d2 = -g_pre / tau.unsqueeze(1)
+        g_tau = (g_pre * d2).sum(dim=1) / (tau * tau)
+        g_lt = (g_tau * torch.sigmoid(log_temp.float())).to(log_temp.dtype)
+
+        c = (g_d2.unsqueeze(-1).unsqueeze(-1) * t_seed).sum(dim=1).double()       # [E, D(b), D(a)]
+        gap = lam_s.unsqueeze(1) - lam_s.unsqueeze(2)                            # [E, b, a] = lam_a - lam_b
+        k = torch.where(gap.abs() > 0, c / torch.where(gap.abs() > 0, gap, torch.ones_like(gap)),
+                        torch.zeros_like(c))
+        v64 = v_s.double()
+        g_gram = v64.transpose(1, 2) @ k @ v64                                   # [E, D, D]
+        p64 = proj_s.double()
+        w_tok = (p64.t() @ (g_gram + g_gram.transpose(1, 2)) @ p64).float()      # [E, D_s, D_s]
+        grads = []
+        for i in range(E):
+            s = student[i]
+            # centring z = s P^T over rows == centring s (linear map), so d loss / d s = (s - mean) W
+            centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
+            grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).view_as(s).to(s.dtype))
+        n_teacher = len(ctx.needs_input_grad) - 4 - E
+        return (g_lt, None, None, None, *grads, *([None] * n_teacher))
+
+
+def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_temperatures):
+    """-> (weights [E, L] with grad, ranks int32 [L] on device, pre_softmax [E, L])."""
+    student = [t.contiguous() for t in student_tokens]
+    teacher = [t.detach().contiguous() for t in teacher_tokens]
+    return _SelectorWeightsFn.apply(log_temperatures, proj_s, proj_t, len(student), *student, *teacher)
+
+
+# --------------------------------------------------------------------------- #
+# mixing
+# --------------------------------------------------------------------------- #
+class _MixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, *layers):
+        ops = get_ops()
+        ctx.layers = layers
+        return ops.mix_tokens(list(layers), w.detach().float())
+
+    @staticmethod
+    def backward(ctx, g):
+        ops = get_ops()
+        dots = ops.mix_grad_dots(list(ctx.layers), g.contiguous().float())
+        return (dots.float(), *([None] * len(ctx.layers)))
+
+
+def mix_layers(w: torch.Tensor, layers) -> torch.Tensor:
+    """w [E, L], layers: L same-shape tensors -> [E, *shape] fp32 (grad flows to w only)."""
+    return _MixFn.apply(w, *[t.detach().contiguous() for t in layers])
+
+
+# --------------------------------------------------------------------------- #
+# Procrustes
+# --------------------------------------------------------------------------- #
+def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
+    """nuclear norm [B] and polar factor G = U V^T [B, D_s, D_t] of cross = s_w^T t_w.
+
+    cross and its Gram are formed in fp64; the pivoted Cholesky factor L (cross = L Q2,
+    Q2 = L^-1 cross with orthonormal rows) is diagonalised by the fp32 Jacobi:
+    L J1 = U Sigma.  The right factor J1 comes from a triangular solve with the graded L
+    (never from a division by sigma), so (U, J1) is a consistent pair and
+    G = U J1^T Q2 is orthonormal to working precision.
+    """
+    ops = get_ops()
+    d_s = s_w.shape[-1]
+    if not ops.jacobi_fits(d_s, d_s):
+        raise BasdShapeError(f"Procrustes core {d_s}x{d_s} does not fit the LDS-resident Jacobi")
+    cross = s_w.double().transpose(1, 2) @ t_w.double()                 # [B, D_s, D_t]
+    mx = cross @ cross.transpose(1, 2)
+    mx = 0.5 * (mx + mx.transpose(1, 2))
+    w0, lwork, piv, rank = ops.pchol(mx, PCHOL_TOL)
+    sigma, _ = ops.jacobi_svd(w0, d_s)                                  # w0[:, i, :d_s] = sigma_i u_i
+    b = s_w.shape[0]
+    pv = piv.long()
+    steps = torch.arange(d_s, device=s_w.device)
+    live = (steps.unsqueeze(0) < rank.unsqueeze(1))                     # [B, k]
+    # L with rows in pivot order: lp[b, r', k] = lwork[b, k, piv[r']]
+    lp = lwork.gather(2, pv.unsqueeze(1).expand(b, d_s, d_s)).transpose(1, 2).contiguous()
+    lp = lp * live.unsqueeze(1)
+    lp = lp + torch.diag_embed((~live).double())
+    wf_p = w0[:, :, :d_s].double().gather(2, pv.unsqueeze(1).expand(b, d_s, d_s)).transpose(1, 2)  # [B, r', i]
+    j1 = torch.linalg.solve_triangular(lp, wf_p, upper=False) * live.unsqueeze(-1)      # [B, k, i]
+    u = torch.where(sigma.unsqueeze(-1) > 0, w0[:, :, :d_s] / sigma.clamp_min(1e-30).unsqueeze(-1),
+                    torch.zeros(1, device=s_w.device))                  # [B, i, r]
+    theta = (u.double().transpose(1, 2) @ j1.transpose(1, 2)).float()   # [B, r, k] = polar(L)
+    cross_p = cross.gather(1, pv.unsqueeze(-1).expand(b, d_s, cross.shape[-1]))
+    q2 = torch.linalg.solve_triangular(lp, cross_p, upper=False) * live.unsqueeze(-1)
+    g = theta @ q2.float()                                              # [B, D_s, D_t]
+    return sigma.sum(dim=-1), g
+
+
+class _ProcrustesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, t, imp):
+        ops = get_ops()
+        n_s, n_t = s.shape[1], t.shape[1]
+        s_w, t_w, a, tr = ops.procrustes_prep(s, t, imp)
+        nuc, g = _polar_of_cross(s_w, t_w)
+        ctx.save_for_backward(s_w, t_w, a, g, imp)
+        ctx.n_t = n_t
+        ctx.s_dtype = s.dtype
+        return tr[:, 0] + tr[:, 1] - 2.0 * nuc
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        s_w, t_w, a, g, imp = ctx.saved_tensors
+        n_s, n_t = s_w.shape[1], ctx.n_t
+        gl = g_loss.float().view(-1, 1, 1)
+        g_sw = 2.0 * gl * (s_w - t_w @ g.transpose(1, 2))
+        g_tw = 2.0 * gl * (t_w - s_w @ g)
+        root = a.sqrt().unsqueeze(-1)
+        g_s = (root * g_sw).to(ctx.s_dtype)
+        g_t = root * g_tw
+        g_a = ((g_sw * s_w).sum(-1) + (g_tw * t_w).sum(-1)) / (2.0 * a)
+        if n_t != n_s:
+            r = resample_matrix(n_t, n_s, s_w.device)                  # [n_s, n_t]
+            tot = (imp.float() @ r.t()).sum(-1, keepdim=True)
+            g_raw = (g_a - (a * g_a).sum(-1, keepdim=True)) / tot
+            g_imp = g_raw @ r
+            g_t = torch.matmul(r.t(), g_t)
+        else:
+            tot = imp.float().sum(-1, keepdim=True)
+            g_imp = (g_a - (a * g_a).sum(-1, keepdim=True)) / tot
+        return g_s, g_t, g_imp
+
+
+def procrustes(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor) -> torch.Tensor:
+    """Per-sample attention-weighted Procrustes value [B]; differentiable in s, t, imp."""
+    return _ProcrustesFn.apply(s.contiguous(), t.contiguous().float(), imp.contiguous().float())

@@ -1,0 +1,100 @@
+"""Grassmannian layer selector on the HIP kernels.
+
+Mirrors the operator surface of the reference ``src/losses/layer_selector.py``
+(``marchenko_pastur_rank`` :8-20, ``GrassmannianLayerSelector`` :40-152: same
+constructor, buffers ``proj_s``/``proj_t``, parameter ``log_temperatures``,
+``temperatures`` property, ``subspace_ranks`` and ``forward`` signature), with
+its own implementation underneath (``functional.py``).
+
+Differences that are visible to a caller, all documented in DESIGN.md:
+* ranks stay on the device during ``forward`` (no ``.item()``);
+  ``subspace_ranks`` is materialised lazily on first access;
+* ``forward`` returns the mixed attention as a compact ``[B, 1, 1, T]`` tensor
+  (row 0 of a one-head map) that ``geometric_relational_loss`` consumes exactly
+  like the reference's full ``[B, H, T, T]`` mix (the loss only ever reads the
+  CLS row / the query mean, relational.py:22-27);
+* mixing runs in fp32 (the reference mixes in the token dtype, :110).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as BF
+from ._ops import get_ops
+
+
+@torch.no_grad()
+def marchenko_pastur_rank(features: torch.Tensor) -> int:
+    """MP rank of an [M, D] matrix (reference layer_selector.py:8-20), computed on the GPU.
+
+    Returns a Python int like the reference (this entry is the start-up path,
+    src/models/teacher.py:161-177; the train step keeps ranks on the device).
+    """
+    ops = get_ops()
+    m, d = features.shape
+    if d % 16 or d > 256 or d < 32:
+        raise BF.BasdShapeError(f"marchenko_pastur_rank: D={d} must be a multiple of 16 in [32, 256]")
+    eye = torch.eye(d, device=features.device, dtype=torch.float32)
+    gram, _ = ops.token_gram(features.contiguous(), eye)
+    sigma, _, _ = BF.psd_eig(gram.unsqueeze(0))
+    return int(ops.mp_rank(sigma ** 2, m, d, d)[0].item())
+
+
+class GrassmannianLayerSelector(nn.Module):
+    def __init__(self, num_extraction_points: int, student_dim: int, teacher_dim: int):
+        super().__init__()
+        self.student_dim = student_dim
+        proj_s = torch.empty(student_dim, student_dim)
+        proj_t = torch.empty(student_dim, teacher_dim)
+        nn.init.orthogonal_(proj_s)
+        nn.init.orthogonal_(proj_t)
+        self.register_buffer("proj_s", proj_s)
+        self.register_buffer("proj_t", proj_t)
+        self.log_temperatures = nn.Parameter(
+            torch.full((num_extraction_points,), math.log(math.exp(1.0) - 1)))
+        self._ranks_dev: torch.Tensor | None = None
+        self._rank_keys: list[int] = []
+        self.last_weights: torch.Tensor | None = None
+        self.last_pre_softmax: torch.Tensor | None = None
+
+    @property
+    def temperatures(self) -> torch.Tensor:
+        return F.softplus(self.log_temperatures)
+
+    @property
+    def subspace_ranks(self) -> dict[int, int]:
+        """{teacher layer index: k_j}; reading it synchronises with the device."""
+        if self._ranks_dev is None:
+            return {}
+        return dict(zip(self._rank_keys, self._ranks_dev.tolist()))
+
+    def mixing_weights(self, student_tokens_per_layer, all_teacher_tokens, extraction_indices):
+        teacher_indices = sorted(all_teacher_tokens.keys())
+        weights, ranks, pre = BF.selector_weights(
+            [student_tokens_per_layer[l] for l in extraction_indices],
+            [all_teacher_tokens[j] for j in teacher_indices],
+            self.proj_s, self.proj_t, self.log_temperatures)
+        self._ranks_dev, self._rank_keys = ranks, teacher_indices
+        self.last_weights, self.last_pre_softmax = weights.detach(), pre.detach()
+        return weights, teacher_indices
+
+    def forward(self, student_tokens_per_layer, all_teacher_tokens, all_teacher_attns,
+                extraction_indices, *, has_cls_token: bool = True):
+        weights, teacher_indices = self.mixing_weights(
+            student_tokens_per_layer, all_teacher_tokens, extraction_indices)
+        mixed = BF.mix_layers(weights, [all_teacher_tokens[j] for j in teacher_indices])
+        imp = torch.stack([BF.importance_from_attention(all_teacher_attns[j], has_cls_token)
+                           for j in teacher_indices])                       # [L, B, N_t]
+        mixed_imp = torch.einsum("el,lbn->ebn", weights, imp)
+        mixed_tokens, mixed_attns = {}, {}
+        for i, l in enumerate(extraction_indices):
+            mixed_tokens[l] = mixed[i]
+            row = mixed_imp[i]
+            if has_cls_token:       # compact map whose [:, :, 0, 1:] is the importance vector
+                row = torch.cat([torch.zeros_like(row[:, :1]), row], dim=1)
+            mixed_attns[l] = row.view(row.shape[0], 1, 1, row.shape[1])
+        return mixed_tokens, mixed_attns
