@@ -22,6 +22,7 @@
  *   basd_mix_tokens        layer_selector.py:110-112 (+ torch.stack :128-129 eliminated)
  *   basd_procrustes_prep   src/losses/relational.py:29-46, src/losses/combined.py:9-14
  *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
+ *   basd_sf_adamw_step     schedulefree.AdamWScheduleFree.step  src/training/trainer.py:54-58,158
  */
 #ifndef BASD_HIP_H
 #define BASD_HIP_H
@@ -109,6 +110,18 @@ int basd_procrustes_prep(const void* s, int s_dtype, const float* t, const float
  * result independent of the arrival order to ~1e-16). */
 int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int L, int E,
                        const float* g, int64_t elems, double* dots, void* stream);
+
+/* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
+ * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:
+ *   v = b2 v + (1-b2) g^2 ; gn = g / (sqrt(v / bias_correction2) + eps) + wd * y
+ *   y = lerp(y, z, ckp1) + lr (b1 (1 - ckp1) - 1) gn ; z = z - lr gn
+ * ckp1 / bias_correction2 / lr are the per-step scalars computed on the host. */
+int basd_sf_adamw_step(float* y, const float* g, float* z, float* v, int64_t n, double lr,
+                       double beta1, double beta2, double eps, double weight_decay, double ckp1,
+                       double bias_correction2, void* stream);
+
+/* y <- y + w (z - y): optimizer.train() / optimizer.eval() switch (trainer.py:180,184). */
+int basd_lerp(float* y, const float* z, int64_t n, float w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,16 @@ def procrustes_prep(s, t, imp):
     t_w = wc.sqrt() * (t - (wc * t).sum(1, keepdim=True))
     tr = torch.stack([(s_w.double() ** 2).sum((1, 2)), (t_w.double() ** 2).sum((1, 2))], dim=1).float()
     return s_w.contiguous(), t_w.contiguous(), a, tr
+
+
+def sf_adamw_step(y, g, z, v, *, lr, beta1, beta2, eps, weight_decay, ckp1, bias_correction2):
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    denom = (v / bias_correction2).sqrt_().add_(eps)
+    gn = g / denom + weight_decay * y
+    y.lerp_(z, ckp1)
+    y.add_(gn, alpha=lr * (beta1 * (1 - ckp1) - 1))
+    z.sub_(gn, alpha=lr)
+
+
+def lerp_(y, z, w):
+    y.add_(z - y, alpha=w)

@@ -1,0 +1,105 @@
+"""Plumbing of the whole train step on CPU (BASELINE config c1: DeiT-Tiny student,
+ViT-Small teacher, 64 random 3x32x32 images), with the HIP kernels replaced by the
+test-only emulation.  Checks the reference's operator surface end to end; the
+numerics of the kernels are covered by the -m gpu tests."""
+import os
+
+import pytest
+import torch
+
+from tests import _emul
+
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "vit-bias-aware-structural-distillation_amd", "configs", "config.yaml")
+
+
+@pytest.fixture(autouse=True)
+def _emulated_kernels():
+    from basd_amd.losses import _ops
+    _ops.set_ops(_emul)
+    yield
+    _ops.set_ops(None)
+
+
+def _c1_config(batch=16):
+    from basd_amd.config import load_config
+    return load_config(CFG, "basd_cifar100", [f"data.batch_size={batch}", "training.num_epochs=1",
+                                              "model.drop_path_rate=0.0"])
+
+
+def test_config_resolvers_and_reference_yaml():
+    from basd_amd.config import load_config
+    cfg = load_config(CFG)
+    assert cfg.model.num_classes == 1000
+    assert cfg.training.label_smoothing == pytest.approx(1e-3)
+    assert cfg.data.eval_crop_ratio == pytest.approx(224 / 256)
+    c1 = _c1_config()
+    assert (c1.model.vit.img_size, c1.model.vit.patch_size, c1.model.num_classes) == (32, 4, 100)
+    assert c1.training.learning_rate == pytest.approx(5e-4)
+
+
+def test_c1_train_steps_run_and_learn_on_cpu():
+    from basd_amd.train import SyntheticLoader, build
+    torch.manual_seed(0)
+    cfg = _c1_config(batch=16)
+    trainer, info = build(cfg, device="cpu")
+    assert info["embed_dim"] == 192 and info["depth"] == 12 and info["num_tokens"] == 64 and info["has_cls_token"]
+    assert trainer.basd_loss.token_layers == [0, 4, 7, 11]
+    trainer.use_mixup = False
+    trainer.autocast_dtype = torch.bfloat16
+    loader = SyntheticLoader(16, 32, 100, steps=3, device="cpu")
+    trainer.optimizer.train()
+    trainer.model.train()
+    before = trainer.flat.data.clone()
+    losses = []
+    for batch in loader:
+        loss, logits = trainer.train_step(batch)
+        assert torch.isfinite(loss)
+        assert logits.shape == (16, 100)
+        losses.append(float(loss))
+    assert not torch.equal(before, trainer.flat.data)
+    assert trainer.optimizer.k == 3
+    ranks = trainer.basd_loss.layer_selector.subspace_ranks
+    assert sorted(ranks) == list(range(12)) and min(ranks.values()) >= 1
+    # gradient buffer is zeroed and parameters are still views of the flat buffer
+    assert float(trainer.flat.grad.abs().max()) == 0.0
+    p0 = next(trainer.model.parameters())
+    assert p0.data_ptr() == trainer.flat.data.data_ptr()
+    # temperatures are trained together with the student (reference trainer.py:74-76)
+    lt = trainer.basd_loss.layer_selector.log_temperatures
+    assert not torch.allclose(lt.detach(), torch.full_like(lt, 0.5413248546129181))
+
+
+def test_teacher_tap_equals_full_attention_map():
+    """importance tap == CLS row (head mean) of the map the reference hook builds."""
+    from basd_amd.models import extract_intermediates, load_teacher, make_attn_capture_hook
+    t = load_teacher("vit_small_patch16_224", 32, device="cpu", patch_size=4, dtype=torch.float32)
+    x = torch.randn(3, 3, 32, 32)
+    maps, hooks = {}, []
+    for i, path in enumerate(t.layer_paths):
+        hooks.append(t.model.get_submodule(f"{path}.attn").register_forward_hook(make_attn_capture_hook(maps, i)))
+    tokens, imp = extract_intermediates(t, x)
+    for h in hooks:
+        h.remove()
+    assert sorted(tokens) == list(range(12)) and tokens[0].shape == (3, 64, 384)
+    for i in range(12):
+        torch.testing.assert_close(imp[i], maps[i][:, :, 0, 1:].mean(1), atol=1e-6, rtol=1e-5)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from basd_amd.train import SyntheticLoader, build
+    cfg = _c1_config(batch=8)
+    cfg.run.output_dir = str(tmp_path)
+    trainer, _ = build(cfg, device="cpu")
+    trainer.use_mixup = False
+    trainer.optimizer.train()
+    for batch in SyntheticLoader(8, 32, 100, steps=1, device="cpu"):
+        trainer.train_step(batch)
+    trainer.save_checkpoint("latest", 0)
+    trainer.save_weights("final_model.pth", 0)
+    snap = trainer.flat.data.clone()
+    trainer.flat.data.add_(1.0)
+    assert trainer.load_checkpoint(str(tmp_path / cfg.run.name / "checkpoints" / "latest")) == 1
+    torch.testing.assert_close(trainer.flat.data, snap)
+    sd = torch.load(tmp_path / cfg.run.name / "checkpoints" / "final_model.pth", weights_only=True)
+    assert "blocks.0.attn.qkv.weight" in sd["model_state_dict"] and "cls_token" in sd["model_state_dict"]

@@ -21,6 +21,7 @@ JACOBI_LDS_BYTES = 163840
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
+    "basd_sf_adamw_step", "basd_lerp",
 )
 
 
@@ -211,3 +212,22 @@ def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor):
                                       _ptr(s_w), _ptr(t_w), _ptr(a), _ptr(tr), _stream()),
            "basd_procrustes_prep")
     return s_w, t_w, a, tr
+
+
+def sf_adamw_step(y, g, z, v, *, lr, beta1, beta2, eps, weight_decay, ckp1, bias_correction2) -> None:
+    """In-place fused Schedule-Free AdamW step on flat fp32 buffers (all same length)."""
+    _need_cuda(y, g, z, v)
+    n = y.numel()
+    assert g.numel() == n and z.numel() == n and v.numel() == n
+    for t in (y, g, z, v):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    f = ctypes.c_double
+    _check(lib().basd_sf_adamw_step(_ptr(y), _ptr(g), _ptr(z), _ptr(v), ctypes.c_int64(n), f(lr), f(beta1),
+                                    f(beta2), f(eps), f(weight_decay), f(ckp1), f(bias_correction2), _stream()),
+           "basd_sf_adamw_step")
+
+
+def lerp_(y, z, w: float) -> None:
+    _need_cuda(y, z)
+    assert y.dtype == torch.float32 and z.dtype == torch.float32 and y.numel() == z.numel()
+    _check(lib().basd_lerp(_ptr(y), _ptr(z), ctypes.c_int64(y.numel()), ctypes.c_float(w), _stream()), "basd_lerp")

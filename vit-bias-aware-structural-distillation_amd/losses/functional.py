@@ -237,8 +237,12 @@ def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
     u = torch.where(sigma.unsqueeze(-1) > 0, w0[:, :, :d_s] / sigma.clamp_min(1e-30).unsqueeze(-1),
                     torch.zeros(1, device=s_w.device))                  # [B, i, r]
     theta = (u.double().transpose(1, 2) @ j1.transpose(1, 2)).float()   # [B, r, k] = polar(L)
+    # Q2 = L^-1 cross through an explicit fp64 inverse (batched dtrsm with 768 right-hand sides
+    # exhausts rocBLAS' workspace at batch 256); L is graded, fp64 keeps the inverse accurate
+    eye = torch.eye(d_s, device=s_w.device, dtype=torch.float64).expand(b, d_s, d_s)
+    l_inv = torch.linalg.solve_triangular(lp, eye, upper=False)
     cross_p = cross.gather(1, pv.unsqueeze(-1).expand(b, d_s, cross.shape[-1]))
-    q2 = torch.linalg.solve_triangular(lp, cross_p, upper=False) * live.unsqueeze(-1)
+    q2 = (l_inv @ cross_p) * live.unsqueeze(-1)
     g = theta @ q2.float()                                              # [B, D_s, D_t]
     return sigma.sum(dim=-1), g
 

@@ -1,0 +1,186 @@
+"""Plain ViT / DeiT / DINOv2-style vision transformer for the BASD train step.
+
+The reference takes its blocks from ``timm==1.0.24`` (``src/train.py:51``,
+``src/models/teacher.py:118``), which is not part of the reference repository
+and not installed here: this is an own implementation of the public ViT
+definition, constrained by what the reference itself assumes of it --
+``blocks`` container, ``attn.qkv`` single Linear with ``reshape(B,N,3,nh,hd)``
+split order, ``attn.num_heads``, scale ``hd**-0.5``, CLS token at index 0
+(teacher.py:33-37,46-50,156-157; trainer.py:29).  Parameter names follow timm
+(``cls_token``, ``pos_embed``, ``patch_embed.proj``, ``blocks.i.norm1``,
+``attn.qkv``, ``attn.proj``, ``ls1.gamma``, ``mlp.fc1`` ...) so that
+``model_state_dict`` files are interchangeable (trainer.py:105-111, eval.py:29-30).
+
+Round 1: GEMMs / attention go through PyTorch-ROCm library kernels (hipBLASLt,
+SDPA) under bf16 autocast; the per-block CLS-row importance tap is computed
+from the block's own q/k (no duplicate QKV GEMM, no [B,H,T,T] map).  Parity of
+the ViT arithmetic itself is UNPINNED by the reference (it has no tests and
+timm is absent) -- see DESIGN.md.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+
+class DropPath(nn.Module):
+    def __init__(self, p: float = 0.0):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if self.p == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.p
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class LayerScale(nn.Module):
+    def __init__(self, dim: int, init_values: float):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class Attention(nn.Module):
+    def __init__(self, dim: int, num_heads: int, qkv_bias: bool = True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.tap: dict | None = None       # set by the teacher tap: {"has_cls": bool, "out": tensor}
+
+    def forward(self, x):
+        b, t, c = x.shape
+        qkv = self.qkv(x).reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.unbind(0)
+        if self.tap is not None:
+            self.tap["out"] = self._importance(q, k, self.tap["has_cls"])
+        out = F.scaled_dot_product_attention(q, k, v)
+        return self.proj(out.transpose(1, 2).reshape(b, t, c))
+
+    def _importance(self, q, k, has_cls: bool):
+        """Head-averaged token importance [B, N]: the only part of softmax(QK^T/sqrt(hd)) the
+        loss reads (src/losses/relational.py:22-27; teacher.py:33-37 builds the full map)."""
+        if has_cls:
+            logits = (q[:, :, :1].float() @ k.float().transpose(-2, -1)) * self.scale   # [B,H,1,T]
+            return logits.softmax(dim=-1)[:, :, 0, 1:].mean(dim=1)
+        attn = ((q.float() @ k.float().transpose(-2, -1)) * self.scale).softmax(dim=-1)
+        return attn.mean(dim=(1, 2))
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim: int, hidden: int):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, drop_path=0.0, init_values=None, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads)
+        self.ls1 = LayerScale(dim, init_values) if init_values else nn.Identity()
+        self.drop_path1 = DropPath(drop_path)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.ls2 = LayerScale(dim, init_values) if init_values else nn.Identity()
+        self.drop_path2 = DropPath(drop_path)
+
+    def forward(self, x):
+        x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
+        return x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size, self.patch_size = img_size, patch_size
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, drop_path_rate=0.0, init_values=None, class_token=True):
+        super().__init__()
+        self.embed_dim = self.num_features = embed_dim
+        self.num_classes = num_classes
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        n = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if class_token else None
+        self.pos_embed = nn.Parameter(torch.randn(1, n + int(class_token), embed_dim) * 0.02)
+        dpr = [drop_path_rate * i / max(depth - 1, 1) for i in range(depth)]
+        self.blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, dpr[i], init_values) for i in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        self.grad_checkpointing = False
+        if self.cls_token is not None:
+            nn.init.normal_(self.cls_token, std=1e-6)
+
+    def set_grad_checkpointing(self, enable: bool = True):
+        self.grad_checkpointing = enable
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        if self.cls_token is not None:
+            x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x], dim=1)
+        x = x + self.pos_embed.to(x.dtype)
+        for blk in self.blocks:
+            if self.grad_checkpointing and self.training and torch.is_grad_enabled():
+                x = checkpoint(blk, x, use_reentrant=False)
+            else:
+                x = blk(x)
+        return self.norm(x)
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        x = x[:, 0] if self.cls_token is not None else x.mean(dim=1)
+        return self.head(x)
+
+
+# name -> (embed_dim, depth, heads, patch, layerscale init)
+VIT_PRESETS = {
+    "deit_tiny_patch16_224": (192, 12, 3, 16, None),
+    "deit_small_patch16_224": (384, 12, 6, 16, None),
+    "deit_base_patch16_224": (768, 12, 12, 16, None),
+    "vit_tiny_patch16_224": (192, 12, 3, 16, None),
+    "vit_small_patch16_224": (384, 12, 6, 16, None),
+    "vit_base_patch16_224": (768, 12, 12, 16, None),
+    "vit_large_patch16_224": (1024, 24, 16, 16, None),
+    "vit_huge_patch14_224": (1280, 32, 16, 14, None),
+    "dinov2_vits14": (384, 12, 6, 14, 1.0),
+    "dinov2_vitb14": (768, 12, 12, 14, 1.0),
+    "dinov2_vitl14": (1024, 24, 16, 14, 1.0),
+}
+
+
+def create_vit(name: str, *, num_classes: int, img_size: int, drop_path_rate: float = 0.0,
+               patch_size: int | None = None, **overrides) -> VisionTransformer:
+    """timm.create_model stand-in for the presets above; ``overrides`` are the reference's
+    ``model.arch_overrides`` keys (embed_dim, depth, num_heads, mlp_ratio; src/train.py:57-66)."""
+    if name not in VIT_PRESETS:
+        raise ValueError(f"unknown ViT preset {name!r}; known: {sorted(VIT_PRESETS)}")
+    dim, depth, heads, patch, ls = VIT_PRESETS[name]
+    kw = dict(embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4.0)
+    kw.update({k: v for k, v in overrides.items() if k in ("embed_dim", "depth", "num_heads", "mlp_ratio")})
+    return VisionTransformer(img_size=img_size, patch_size=patch_size or patch, num_classes=num_classes,
+                             drop_path_rate=drop_path_rate, init_values=ls, **kw)

@@ -1,0 +1,123 @@
+"""``basd-train`` driver on the MI355X path (reference ``src/train.py:72-160``).
+
+Keeps ``_apply_fan_in_init`` (:19-32), ``_create_student`` (:35-54) and
+``_derive_from_teacher`` (:57-66) semantics.  Dataset streaming, teacher weight
+download and the eval suite need the network and are out of scope (SURVEY
+section 2): the driver trains on synthetic dual-view batches unless the caller
+passes loaders, with teacher weights random-initialised or loaded from
+``basd.teacher_weights``.
+
+    python -m basd_amd.train --config configs/config.yaml [--experiment NAME] [key=value ...]
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .config import load_config
+from .models.teacher import TeacherModel, estimate_intrinsic_dim, load_teacher, probe_model
+from .models.vit import create_vit
+from .training.trainer import Trainer
+
+
+def _apply_fan_in_init(model: nn.Module) -> None:
+    for m in model.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=(2.0 / m.weight.shape[1]) ** 0.5)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Conv2d):
+            fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+            nn.init.normal_(m.weight, std=(2.0 / fan_out) ** 0.5)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+
+def _create_student(model_name: str, *, num_classes: int, drop_path_rate: float, img_size: int,
+                    arch_overrides: dict | None = None, patch_size: int | None = None,
+                    grad_checkpointing: bool = False, device="cuda") -> nn.Module:
+    model = create_vit(model_name, num_classes=num_classes, drop_path_rate=drop_path_rate, img_size=img_size,
+                       patch_size=patch_size, **(arch_overrides or {}))
+    _apply_fan_in_init(model)
+    # the reference turns activation checkpointing on (train.py:53) to fit 24-80 GB parts; with
+    # 288 GB of HBM3E it only costs a second student forward, so it is opt-in here
+    model.set_grad_checkpointing(grad_checkpointing)
+    return model.to(device)
+
+
+def _derive_from_teacher(teacher: TeacherModel, intrinsic_dim: int) -> dict:
+    head_dim = teacher.embed_dim // teacher.heads_per_layer[0]
+    d_s = min(math.ceil(intrinsic_dim / head_dim) * head_dim, teacher.embed_dim)
+    return {"embed_dim": d_s, "depth": teacher.depth, "num_heads": d_s // head_dim, "mlp_ratio": teacher.mlp_ratio}
+
+
+class SyntheticLoader:
+    """Device-resident dual-view batches with the reference's batch contract
+    (src/data/datasets.py:152-156): {"clean", "augmented", "label"}."""
+
+    def __init__(self, batch_size, img_size, num_classes, steps, device, seed=1234):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        base = torch.randn(batch_size, 3, img_size, img_size, generator=g)
+        # low-frequency structure so that teacher tokens are not pure noise (MP rank >= 1)
+        yy, xx = torch.meshgrid(torch.linspace(-1, 1, img_size), torch.linspace(-1, 1, img_size), indexing="ij")
+        phase = torch.rand(batch_size, 3, 1, 1, generator=g) * 6.28
+        base = base + 2.0 * torch.sin(3.0 * xx + phase) * torch.cos(2.0 * yy + phase)
+        self.clean = base.to(device)
+        self.aug = (base + 0.1 * torch.randn(base.shape, generator=g)).to(device)
+        self.label = torch.randint(0, num_classes, (batch_size,), generator=g).to(device)
+        self.steps = steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            yield {"clean": self.clean, "augmented": self.aug, "label": self.label}
+
+    def __len__(self):
+        return self.steps
+
+
+def build(config, device="cuda"):
+    torch.manual_seed(config.run.seed)
+    img_size = config.model.vit.img_size
+    patch = config.model.vit.patch_size
+    teacher = load_teacher(config.basd.teacher_model_name, img_size=img_size, device=device,
+                           weights=config.basd.get("teacher_weights"), seed=config.run.seed,
+                           patch_size=config.basd.get("teacher_patch_size"))
+    arch = dict(config.model.get("arch_overrides") or {})
+    if not arch and teacher.feature_format == "token" and config.basd.get("derive_student", False):
+        calib = torch.randn(math.ceil(10 * teacher.embed_dim / (img_size // patch) ** 2), 3, img_size, img_size,
+                            device=device)
+        arch = _derive_from_teacher(teacher, estimate_intrinsic_dim(teacher, calib))
+        config.model.arch_overrides = arch
+    student = _create_student(config.model.student_preset, num_classes=config.model.num_classes,
+                              drop_path_rate=config.model.drop_path_rate, img_size=img_size,
+                              arch_overrides=arch, patch_size=patch, device=device,
+                              grad_checkpointing=bool(config.model.get("grad_checkpointing", False)))
+    student_info = probe_model(student, img_size)
+    trainer = Trainer(student, config, accelerator=None, teacher=teacher, student_info=student_info)
+    return trainer, student_info
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=os.path.join(os.path.dirname(__file__), "configs", "config.yaml"))
+    ap.add_argument("--experiment", default=None)
+    ap.add_argument("--steps-per-epoch", type=int, default=10)
+    ap.add_argument("overrides", nargs="*")
+    args = ap.parse_args(argv)
+    config = load_config(args.config, args.experiment, args.overrides)
+    trainer, info = build(config)
+    print(f"student_probed embed_dim={info['embed_dim']} depth={info['depth']} num_tokens={info['num_tokens']}")
+    loader = SyntheticLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes,
+                             args.steps_per_epoch, trainer.device)
+    trainer.train(loader, None, start_epoch=0)
+
+
+if __name__ == "__main__":
+    main()

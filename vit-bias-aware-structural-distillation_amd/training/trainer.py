@@ -1,0 +1,153 @@
+"""BASD trainer: the train step of reference ``src/training/trainer.py:133-164``
+on the MI355X path (bf16 ViTs, HIP loss kernels, fused Schedule-Free AdamW,
+bucketed RCCL gradient averaging overlapped with backward).
+
+Operator surface kept from the reference: ``_extract_student`` (:16-37) and
+``Trainer(student_model, config, accelerator, teacher, *, student_info)`` with
+``.model``, ``.optimizer``, ``.basd_loss``, ``.train``, ``.save_checkpoint``,
+``.save_weights``, ``.load_checkpoint`` (:41-211).  ``accelerator`` is accepted
+for signature compatibility and may be None: mixed precision is
+``torch.autocast(bf16)`` and data parallelism is ``GradientReducer``.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from ..losses.combined import BASDLoss
+from ..models.teacher import TeacherModel, extract_intermediates
+from .data_parallel import GradientReducer
+from .mixup import mixup_cutmix
+from .optim import AdamWScheduleFree, FlatParams
+
+
+def _extract_student(model: nn.Module, x: torch.Tensor, layer_indices, *, layer_paths, has_cls_token: bool):
+    """Student forward with token taps at ``layer_indices`` (CLS stripped), reference :16-37."""
+    hooks, captured = [], {}
+    for idx in layer_indices:
+        block = model.get_submodule(layer_paths[idx])
+
+        def make_hook(i):
+            def hook(mod, inp, out):
+                captured[i] = out[:, 1:, :] if has_cls_token else out
+            return hook
+        hooks.append(block.register_forward_hook(make_hook(idx)))
+    try:
+        logits = model(x)
+    finally:
+        for h in hooks:
+            h.remove()
+    return logits, captured
+
+
+class Trainer:
+    def __init__(self, student_model: nn.Module, config, accelerator=None, teacher: TeacherModel = None, *,
+                 student_info: dict, bucket_bytes: int = 32 << 20):
+        self.accelerator = accelerator
+        self.config = config
+        self.device = next(student_model.parameters()).device
+        self.criterion = nn.CrossEntropyLoss(label_smoothing=config.training.label_smoothing)
+        self._teacher = teacher
+        self._student_layer_paths = student_info["layer_paths"]
+        self._student_has_cls = student_info["has_cls_token"]
+        self.basd_loss = BASDLoss(
+            base_criterion=self.criterion, student_dim=student_info["embed_dim"],
+            teacher_dim=teacher.embed_dim, student_depth=student_info["depth"],
+            num_student_tokens=student_info["num_tokens"], config=config.basd,
+            teacher_has_cls_token=teacher.has_cls_token).to(self.device)
+        self.model = student_model
+        # one flat buffer: student parameters first, then the selector temperatures
+        # (the reference adds them as an extra param group inheriting lr / weight decay, :74-76)
+        self.flat = FlatParams(list(student_model.parameters()) + list(self.basd_loss.parameters()))
+        self.optimizer = AdamWScheduleFree(self.flat, lr=config.training.learning_rate,
+                                           weight_decay=config.training.weight_decay)
+        self.reducer = GradientReducer(self.flat, bucket_bytes=bucket_bytes)
+        self.reducer.broadcast_parameters()
+        self.optimizer.z.copy_(self.flat.data)
+        self.best_val_acc = 0.0
+        self.metrics_history = defaultdict(list)
+        self.num_classes = config.model.num_classes
+        self.use_mixup = True
+        self.autocast_dtype = torch.bfloat16
+
+    # ------------------------------------------------------------------ step
+    def train_step(self, batch: dict):
+        """One optimisation step on a device-resident batch {"clean","augmented","label"}."""
+        clean, student_imgs, targets = batch["clean"], batch["augmented"], batch["label"]
+        if self.use_mixup:
+            student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
+        else:
+            mixed_targets = targets
+        with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
+            logits, s_tokens = _extract_student(
+                self.model, student_imgs, self.basd_loss.token_layers,
+                layer_paths=self._student_layer_paths, has_cls_token=self._student_has_cls)
+        t_tokens, t_importance = extract_intermediates(self._teacher, clean)
+        loss = self.basd_loss(logits.float(), mixed_targets, s_tokens, t_tokens, t_importance)
+        loss.backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach(), logits.detach()
+
+    def _train_epoch(self, train_loader):
+        total_loss = torch.tensor(0.0, device=self.device)
+        correct = torch.tensor(0, device=self.device, dtype=torch.long)
+        total = 0
+        for batch in train_loader:
+            batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+            loss, logits = self.train_step(batch)
+            n = batch["label"].size(0)
+            total_loss += loss * n
+            correct += logits.argmax(1).eq(batch["label"]).sum()
+            total += n
+        return {"train_loss": (total_loss / total).item(), "train_acc": 100.0 * (correct / total).item()}
+
+    def train(self, train_loader, val_loader=None, start_epoch: int = 0, evaluate_fn=None):
+        num_epochs = self.config.training.num_epochs
+        for epoch in range(start_epoch, num_epochs):
+            self.optimizer.train()
+            self.model.train()
+            metrics = self._train_epoch(train_loader)
+            self.optimizer.eval()
+            if evaluate_fn is not None and val_loader is not None:
+                metrics.update(evaluate_fn(self.model, val_loader))
+            print(" ".join([f"epoch {epoch + 1}/{num_epochs}"] + [f"{k}={v:.6f}" for k, v in metrics.items()]))
+            for k, v in metrics.items():
+                self.metrics_history[k].append(v)
+            if metrics.get("val_acc", -1.0) > self.best_val_acc:
+                self.best_val_acc = metrics["val_acc"]
+                self.save_checkpoint("best_model", epoch)
+                self.save_weights("best_model.pth", epoch)
+            self.save_checkpoint("latest", epoch)
+        self.save_weights("final_model.pth", num_epochs - 1)
+        return self.metrics_history
+
+    # ----------------------------------------------------------- checkpoints
+    def _ckpt_dir(self) -> Path:
+        d = Path(self.config.run.output_dir) / self.config.run.name / "checkpoints"
+        d.mkdir(parents=True, exist_ok=True)
+        return d
+
+    def save_checkpoint(self, name: str, epoch: int) -> None:
+        d = self._ckpt_dir() / name
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save({"model": self.model.state_dict(), "basd_loss": self.basd_loss.state_dict(),
+                    "optimizer": self.optimizer.state_dict()}, d / "state.pth")
+        torch.save({"epoch": epoch, "best_val_acc": self.best_val_acc,
+                    "metrics_history": dict(self.metrics_history)}, d / "custom_state.pth")
+
+    def save_weights(self, filename: str, epoch: int) -> None:
+        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()}, self._ckpt_dir() / filename)
+
+    def load_checkpoint(self, checkpoint_path: str) -> int:
+        d = Path(checkpoint_path)
+        state = torch.load(d / "state.pth", map_location=self.device, weights_only=False)
+        self.optimizer.load_state_dict(state["optimizer"])     # flat buffer: restores every parameter
+        custom = torch.load(d / "custom_state.pth", map_location=self.device, weights_only=False)
+        self.best_val_acc = custom["best_val_acc"]
+        self.metrics_history = defaultdict(list, custom["metrics_history"])
+        return custom["epoch"] + 1
