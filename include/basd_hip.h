@@ -42,6 +42,7 @@ extern "C" {
 
 #define BASD_DTYPE_F32 0
 #define BASD_DTYPE_BF16 1
+#define BASD_DTYPE_F64 2
 
 /* largest matrix the LDS-resident Jacobi accepts: cols * ld(rows) * 4 <= 160 KiB - scratch */
 #define BASD_JACOBI_MAX_COLS 256
@@ -69,6 +70,12 @@ int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in,
 int basd_pchol_f64(const double* a, int batch, int n, double tol,
                    float* w0, int ld, double* lwork, int32_t* piv, int32_t* rank,
                    void* stream);
+
+/* Inverse of the pivoted Cholesky factor left by basd_pchol_f64, fp64, packed triangle in LDS:
+ * out[b] = L_p^-1 P  ([n, n] row-major; P = pivot permutation, L_p = P L lower triangular), so
+ * out @ M == L_p^-1 (P M) for M with rows in ORIGINAL order.  Rows >= rank[b] are zero. */
+int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank, int batch, int n,
+                   double* out, void* stream);
 
 /* One-sided (Hestenes) Jacobi in LDS on `batch` column-major matrices
  * w[b]: n_cols columns of `ld` floats, first m_rows rows significant
@@ -110,6 +117,16 @@ int basd_procrustes_prep(const void* s, int s_dtype, const float* t, const float
  * result independent of the arrival order to ~1e-16). */
 int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int L, int E,
                        const float* g, int64_t elems, double* dots, void* stream);
+
+/* Batched GEMM with fp64 accumulation on the fp64 matrix cores: C[b] = op(A[b]) op(B[b]).
+ * Row-major, explicit leading dimensions and batch strides (in elements); A/B dtype F32 or F64,
+ * C dtype F32 or F64; trans_x != 0 means the stored matrix is the transpose of op(X).
+ * Replaces the torch.bmm / matmul calls of the Procrustes core that must not round to fp32
+ * (reference src/losses/relational.py:47 forms the cross-covariance in fp32). */
+int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int trans_a,
+                   const void* b, int b_dtype, int64_t b_stride, int ldb, int trans_b,
+                   void* c, int c_dtype, int64_t c_stride, int ldc,
+                   int batch, int M, int N, int K, void* stream);
 
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:

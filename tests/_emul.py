@@ -134,3 +134,28 @@ def sf_adamw_step(y, g, z, v, *, lr, beta1, beta2, eps, weight_decay, ckp1, bias
 
 def lerp_(y, z, w):
     y.add_(z - y, alpha=w)
+
+
+def bgemm_f64(a, b, *, trans_a=False, trans_b=False, out_dtype=torch.float64):
+    a, b = a.double(), b.double()
+    if trans_a:
+        a = a.transpose(1, 2)
+    if trans_b:
+        b = b.transpose(1, 2)
+    return (a @ b).to(out_dtype)
+
+
+def trinv(lwork, piv, rank):
+    batch, n, _ = lwork.shape
+    out = torch.zeros(batch, n, n, dtype=torch.float64)
+    for b in range(batch):
+        r = int(rank[b])
+        pv = piv[b].long()
+        lp = lwork[b].t()[pv]                  # [r', k] lower triangular in pivot order
+        lp = lp.clone()
+        lp[:, r:] = 0.0
+        lp[range(r, n), range(r, n)] = 1.0
+        x = torch.linalg.solve_triangular(lp, torch.eye(n, dtype=torch.float64), upper=False)
+        x[r:] = 0.0
+        out[b][:, pv] = x
+    return out

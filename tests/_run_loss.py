@@ -42,6 +42,7 @@ def check_against_golden(gold, res, kind, layers, *, grad_tol, has_temp_grad=Tru
     assert res["ranks"].tolist() == gold[f"{kind}/ranks"].tolist()
     torch.testing.assert_close(res["weights"], gold[f"{kind}/weights"], atol=2e-6, rtol=0)
     torch.testing.assert_close(res["pre_softmax"], gold[f"{kind}/pre_softmax"], atol=2e-5, rtol=1e-4)
+    print("  geo rel err", ((res["geo"] - gold[f"{kind}/geo"]).abs() / gold[f"{kind}/geo"].abs()).tolist(), "weights max abs err", float((res["weights"] - gold[f"{kind}/weights"]).abs().max()))
     torch.testing.assert_close(res["geo"], gold[f"{kind}/geo"], atol=0, rtol=geo_rtol)
     torch.testing.assert_close(res["ce"], gold[f"{kind}/ce"], atol=0, rtol=1e-5)
     torch.testing.assert_close(res["loss"], gold[f"{kind}/loss"], atol=0, rtol=2e-5)
@@ -55,4 +56,5 @@ def check_against_golden(gold, res, kind, layers, *, grad_tol, has_temp_grad=Tru
         want = gold[f"{kind}/grad_student_{l}"]
         got = res[f"grad_student_{l}"][: want.shape[0]]
         err = rel_l2(got, want)
+        print(f"  grad_student_{l}: rel-L2 error vs reference {err:.2e}")
         assert err < grad_tol, (l, err)

@@ -170,3 +170,36 @@ def test_procrustes_prep(nat, n_t):
     assert torch.allclose(t_w.cpu().double(), t_ref, atol=2e-6)
     assert torch.allclose(tr[:, 0].cpu().double(), (s_ref ** 2).sum((1, 2)), rtol=1e-5)
     assert torch.allclose(tr[:, 1].cpu().double(), (t_ref ** 2).sum((1, 2)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("dt_a,dt_b,dt_c", [(torch.float32, torch.float32, torch.float64),
+                                            (torch.float64, torch.float64, torch.float64),
+                                            (torch.float64, torch.float64, torch.float32)])
+def test_bgemm_f64(nat, ta, tb, dt_a, dt_b, dt_c):
+    g = torch.Generator().manual_seed(7)
+    batch, M, N, K = 3, 70, 130, 53        # ragged vs the 64x64x16 tiling
+    a = torch.randn(batch, *((K, M) if ta else (M, K)), generator=g, dtype=torch.float64).to(dt_a)
+    b = torch.randn(batch, *((N, K) if tb else (K, N)), generator=g, dtype=torch.float64).to(dt_b)
+    c = nat.bgemm_f64(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb, out_dtype=dt_c)
+    ref = (a.double().transpose(1, 2) if ta else a.double()) @ (b.double().transpose(1, 2) if tb else b.double())
+    tol = 1e-12 if dt_c == torch.float64 else 1e-6
+    assert c.dtype == dt_c
+    assert torch.allclose(c.cpu().double(), ref, rtol=0, atol=tol * float(ref.abs().max()) * K ** 0.5)
+
+
+@pytest.mark.parametrize("n,rank", [(32, 32), (32, 20), (192, 192), (192, 100)])
+def test_trinv_matches_triangular_solve(nat, n, rank):
+    g = torch.Generator().manual_seed(n * 7 + rank)
+    z = torch.randn(3, 3 * n, rank, dtype=torch.float64, generator=g) @ torch.randn(3, rank, n, dtype=torch.float64, generator=g)
+    a = z.transpose(1, 2) @ z
+    w0, lwork, piv, rk = nat.pchol(a.cuda())
+    out = nat.trinv(lwork, piv, rk).cpu()
+    assert rk.tolist() == [rank] * 3
+    for b in range(3):
+        pv = piv[b].cpu().long()
+        lp = lwork[b].cpu().t()[pv][:rank, :rank]              # live block, pivot order
+        x = out[b][:, pv]                                       # undo the column scatter
+        assert torch.allclose(x[:rank, :rank] @ lp, torch.eye(rank, dtype=torch.float64), atol=1e-9)
+        assert float(x[rank:].abs().max()) == 0.0 if rank < n else True
+        assert float(torch.triu(x[:rank, :rank], 1).abs().max()) == 0.0

@@ -15,13 +15,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbasd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F64 = 0, 1, 2
 JACOBI_LDS_BYTES = 163840
 
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
-    "basd_sf_adamw_step", "basd_lerp",
+    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64",
 )
 
 
@@ -231,3 +231,31 @@ def lerp_(y, z, w: float) -> None:
     _need_cuda(y, z)
     assert y.dtype == torch.float32 and z.dtype == torch.float32 and y.numel() == z.numel()
     _check(lib().basd_lerp(_ptr(y), _ptr(z), ctypes.c_int64(y.numel()), ctypes.c_float(w), _stream()), "basd_lerp")
+
+
+def bgemm_f64(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
+              out_dtype=torch.float64) -> torch.Tensor:
+    """Batched op(a) @ op(b) with fp64 accumulation; a, b [batch, r, c] fp32/fp64 contiguous."""
+    _need_cuda(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    code = {torch.float32: DTYPE_F32, torch.float64: DTYPE_F64}
+    batch = a.shape[0]
+    M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    K2, N = (b.shape[2], b.shape[1]) if trans_b else (b.shape[1], b.shape[2])
+    assert K == K2 and b.shape[0] == batch, (a.shape, b.shape, trans_a, trans_b)
+    c = torch.empty(batch, M, N, dtype=out_dtype, device=a.device)
+    i64 = ctypes.c_int64
+    _check(lib().basd_bgemm_f64(_ptr(a), code[a.dtype], i64(a.shape[1] * a.shape[2]), a.shape[2], int(trans_a),
+                                _ptr(b), code[b.dtype], i64(b.shape[1] * b.shape[2]), b.shape[2], int(trans_b),
+                                _ptr(c), code[out_dtype], i64(M * N), N, batch, M, N, K, _stream()), "basd_bgemm_f64")
+    return c
+
+
+def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
+    """(lwork, piv, rank) from pchol -> L_p^-1 P  [batch, n, n] fp64 (see basd_trinv_f64)."""
+    _need_cuda(lwork, piv, rank)
+    batch, n, _ = lwork.shape
+    out = torch.empty(batch, n, n, dtype=torch.float64, device=lwork.device)
+    _check(lib().basd_trinv_f64(_ptr(lwork.contiguous()), _ptr(piv.contiguous()), _ptr(rank.contiguous()), batch, n,
+                                _ptr(out), _stream()), "basd_trinv_f64")
+    return out

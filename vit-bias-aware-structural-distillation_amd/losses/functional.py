@@ -211,7 +211,7 @@ def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
 
     cross and its Gram are formed in fp64; the pivoted Cholesky factor L (cross = L Q2,
     Q2 = L^-1 cross with orthonormal rows) is diagonalised by the fp32 Jacobi:
-    L J1 = U Sigma.  The right factor J1 comes from a triangular solve with the graded L
+    L J1 = U Sigma.  The right factor J1 = L^-1 (U Sigma) uses the explicit fp64 inverse of the graded L
     (never from a division by sigma), so (U, J1) is a consistent pair and
     G = U J1^T Q2 is orthonormal to working precision.
     """
@@ -219,31 +219,19 @@ def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
     d_s = s_w.shape[-1]
     if not ops.jacobi_fits(d_s, d_s):
         raise BasdShapeError(f"Procrustes core {d_s}x{d_s} does not fit the LDS-resident Jacobi")
-    cross = s_w.double().transpose(1, 2) @ t_w.double()                 # [B, D_s, D_t]
-    mx = cross @ cross.transpose(1, 2)
+    cross = ops.bgemm_f64(s_w, t_w, trans_a=True)                       # [B, D_s, D_t] fp64
+    mx = ops.bgemm_f64(cross, cross, trans_b=True)
     mx = 0.5 * (mx + mx.transpose(1, 2))
     w0, lwork, piv, rank = ops.pchol(mx, PCHOL_TOL)
     sigma, _ = ops.jacobi_svd(w0, d_s)                                  # w0[:, i, :d_s] = sigma_i u_i
-    b = s_w.shape[0]
-    pv = piv.long()
-    steps = torch.arange(d_s, device=s_w.device)
-    live = (steps.unsqueeze(0) < rank.unsqueeze(1))                     # [B, k]
-    # L with rows in pivot order: lp[b, r', k] = lwork[b, k, piv[r']]
-    lp = lwork.gather(2, pv.unsqueeze(1).expand(b, d_s, d_s)).transpose(1, 2).contiguous()
-    lp = lp * live.unsqueeze(1)
-    lp = lp + torch.diag_embed((~live).double())
-    wf_p = w0[:, :, :d_s].double().gather(2, pv.unsqueeze(1).expand(b, d_s, d_s)).transpose(1, 2)  # [B, r', i]
-    j1 = torch.linalg.solve_triangular(lp, wf_p, upper=False) * live.unsqueeze(-1)      # [B, k, i]
-    u = torch.where(sigma.unsqueeze(-1) > 0, w0[:, :, :d_s] / sigma.clamp_min(1e-30).unsqueeze(-1),
+    l_inv = ops.trinv(lwork, piv, rank)                                 # L_p^-1 P  [B, k, r] fp64
+    wf = w0[:, :, :d_s].contiguous()                                    # [B, i, r] = sigma_i u_i[r]
+    j1 = ops.bgemm_f64(l_inv, wf, trans_b=True)                         # [B, k, i]:  L J1 = U Sigma
+    u = torch.where(sigma.unsqueeze(-1) > 0, wf / sigma.clamp_min(1e-30).unsqueeze(-1),
                     torch.zeros(1, device=s_w.device))                  # [B, i, r]
-    theta = (u.double().transpose(1, 2) @ j1.transpose(1, 2)).float()   # [B, r, k] = polar(L)
-    # Q2 = L^-1 cross through an explicit fp64 inverse (batched dtrsm with 768 right-hand sides
-    # exhausts rocBLAS' workspace at batch 256); L is graded, fp64 keeps the inverse accurate
-    eye = torch.eye(d_s, device=s_w.device, dtype=torch.float64).expand(b, d_s, d_s)
-    l_inv = torch.linalg.solve_triangular(lp, eye, upper=False)
-    cross_p = cross.gather(1, pv.unsqueeze(-1).expand(b, d_s, cross.shape[-1]))
-    q2 = (l_inv @ cross_p) * live.unsqueeze(-1)
-    g = theta @ q2.float()                                              # [B, D_s, D_t]
+    theta = ops.bgemm_f64(u, j1, trans_a=True, trans_b=True, out_dtype=torch.float32)   # [B, r, k] = polar(L)
+    q2 = ops.bgemm_f64(l_inv, cross, out_dtype=torch.float32)           # [B, k, D_t], orthonormal rows
+    g = theta @ q2                                              # [B, D_s, D_t]
     return sigma.sum(dim=-1), g
 
 

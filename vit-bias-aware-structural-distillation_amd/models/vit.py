@@ -114,7 +114,13 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x):
-        return self.proj(x).flatten(2).transpose(1, 2)
+        # non-overlapping patches: the stride-p convolution IS a GEMM on unfolded patches
+        # ([B*N, 3*p*p] x [3*p*p, D]).  Going through F.conv2d lands on MIOpen's untuned
+        # naive bf16 convolution here (24 ms fwd + 31 ms wrw per call at B=256).
+        b, c, h, w = x.shape
+        p = self.patch_size
+        patches = x.reshape(b, c, h // p, p, w // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, c * p * p)
+        return F.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
 
 
 class VisionTransformer(nn.Module):
