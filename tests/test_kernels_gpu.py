@@ -38,7 +38,8 @@ def test_jacobi_singular_values_and_invariants(nat, m, n, batch):
     # column-graded input: one-sided Jacobi keeps RELATIVE accuracy of every singular value
     err = float((sig / ref - 1).abs().max())
     print(f"jacobi {m}x{n}: max rel sigma error {err:.2e}, sweeps {sweeps.tolist()}")
-    assert err < 5e-6
+    # relative accuracy is eps * kappa(B) for A = B D; a square Gaussian B (192x192) has kappa ~ 1e3
+    assert err < (2e-5 if m == n else 5e-6)
     wf = w.cpu().double()[:, :, :m].transpose(1, 2)          # [batch, m, n] = U Sigma
     gram = wf.transpose(1, 2) @ wf
     off = gram - torch.diag_embed(torch.diagonal(gram, dim1=1, dim2=2))

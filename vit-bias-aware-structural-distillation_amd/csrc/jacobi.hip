@@ -33,6 +33,8 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
   if (tid < 2) s_flag[tid] = 0;
   __syncthreads();
 
+  // rows m..ld-1 are zero padding (kept zero by any rotation): never loaded / rotated / stored
+  const int mrows = (m + 3) & ~3;
   const int n_even = n + (n & 1);
   const int R = n_even - 1;
   const int npairs = n_even >> 1;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
         float alpha = 0.f, beta = 0.f, gamma = 0.f;
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
-          if (sub * 4 + 32 * ch < ld) {
+          if (sub * 4 + 32 * ch < mrows) {
             a[ch] = *reinterpret_cast<const float4*>(cp + 32 * ch);
             b[ch] = *reinterpret_cast<const float4*>(cq + 32 * ch);
             alpha = fmaf(a[ch].x, a[ch].x, fmaf(a[ch].y, a[ch].y, fmaf(a[ch].z, a[ch].z, fmaf(a[ch].w, a[ch].w, alpha))));
@@ -64,19 +66,26 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
         alpha = group8_sum(alpha);
         beta = group8_sum(beta);
         gamma = group8_sum(gamma);
-        if (fabsf(gamma) > tol * sqrtf(alpha * beta) && gamma != 0.f) {
+        // |gamma| > tol sqrt(alpha beta), without the sqrt
+        if (gamma * gamma > tol * tol * alpha * beta && gamma != 0.f) {
           rotated = true;
-          const float zeta = (beta - alpha) / (2.f * gamma);
-          const float tt = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(fmaf(zeta, zeta, 1.f)));
-          const float c = 1.0f / sqrtf(fmaf(tt, tt, 1.f));
+          // The rotation ANGLE may be approximate (hardware rcp / sqrt, 1 ulp): any t gives an exact
+          // plane rotation as long as (c, s) are consistent.  Only c = (1 + t^2)^(-1/2) is refined
+          // (one Newton step on v_rsq_f32) so that c^2 + s^2 = 1 to rounding.  This removes four
+          // IEEE divide / sqrt expansions from the per-step dependent chain.
+          const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
+          const float tt = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.f)));
+          const float w1 = fmaf(tt, tt, 1.f);
+          float c = __builtin_amdgcn_rsqf(w1);
+          c = c * fmaf(-0.5f * w1, c * c, 1.5f);
           const float s = c * tt;
           // Rutishauser form x' = x - s (y + tau x), y' = y + s (x - tau y), tau = s / (1 + c):
           // c = 1 - s*tau is never rounded to 1, so small-angle rotations (t^2 < eps) do not
           // inflate the column norms (a plain c*x - s*y update biased sigma by +2e-5 at n = 192)
-          const float tau = s / (1.0f + c);
+          const float tau = s * __builtin_amdgcn_rcpf(1.0f + c);
 #pragma unroll
           for (int ch = 0; ch < MAXCH; ++ch) {
-            if (sub * 4 + 32 * ch < ld) {
+            if (sub * 4 + 32 * ch < mrows) {
               float4 na, nb;
               na.x = fmaf(-s, fmaf(tau, a[ch].x, b[ch].x), a[ch].x); nb.x = fmaf(s, fmaf(-tau, b[ch].x, a[ch].x), b[ch].x);
               na.y = fmaf(-s, fmaf(tau, a[ch].y, b[ch].y), a[ch].y); nb.y = fmaf(s, fmaf(-tau, b[ch].y, a[ch].y), b[ch].y);
@@ -148,7 +157,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   const int npairs = (n_cols + 1) / 2;
   int threads = ((npairs * 8 + 63) / 64) * 64;
   if (threads < 64) threads = 64;
-  const int chunks = (ld + 31) / 32;
+  const int chunks = (((m_rows + 3) & ~3) + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
 #define BASD_LAUNCH_JACOBI(MC)                                                                     \
   do {                                                                                             \
@@ -159,6 +168,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   } while (0)
   if (chunks <= 2) BASD_LAUNCH_JACOBI(2);
   else if (chunks <= 4) BASD_LAUNCH_JACOBI(4);
+  else if (chunks <= 6) BASD_LAUNCH_JACOBI(6);
   else if (chunks <= 7) BASD_LAUNCH_JACOBI(7);
   else if (chunks <= 10) BASD_LAUNCH_JACOBI(10);
   else return fail(BASD_ERR_SHAPE, "jacobi_svd: ld %d > 320 rows unsupported", ld);

@@ -16,6 +16,125 @@
 
 namespace basd {
 
+__device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }
+
+// LDS-resident version: the lower triangle of A lives packed in LDS (fp64, n(n+1)/2 doubles,
+// 148 KiB at n = 192) and is overwritten column by column with the factor (left-looking, so
+// the slow LDS writes stay at n^2/2 while the reads are n^3/3).  Diagonal pivoting is done
+// with physical symmetric swaps inside the packed triangle; `perm` tracks original indices
+// and the outputs are scattered back to ORIGINAL row order at the end.
+// 768 threads = 192 rows x 4 j-slices.
+__global__ __launch_bounds__(768) void pchol_lds_kernel(const double* __restrict__ a_all, int n, double tol,
+                                                        float* __restrict__ w0_all, int ld,
+                                                        double* __restrict__ lw_all,
+                                                        int32_t* __restrict__ piv_all,
+                                                        int32_t* __restrict__ rank_all) {
+  extern __shared__ __align__(16) double X[];                 // packed lower triangle
+  const int tri_n = n * (n + 1) / 2;
+  double* s_d = X + tri_n;                                     // [n] residual diagonal
+  double* s_redv = s_d + n;                                    // [16]
+  int* s_perm = reinterpret_cast<int*>(s_redv + 16);           // [n]
+  int* s_redi = s_perm + n;                                    // [16]
+  int* s_ctl = s_redi + 16;                                    // [2]: pivot position, stop flag
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const double* A = a_all + (size_t)blockIdx.x * n * n;
+  double* Lw = lw_all + (size_t)blockIdx.x * n * n;
+  float* W0 = w0_all + (size_t)blockIdx.x * n * ld;
+  int32_t* piv = piv_all + (size_t)blockIdx.x * n;
+
+  for (int e = tid; e < n * n; e += nt) {
+    const int i = e / n, j = e - i * n;
+    if (j <= i) X[tri(i, j)] = A[e];
+  }
+  for (int i = tid; i < n; i += nt) { s_d[i] = A[(size_t)i * n + i]; s_perm[i] = i; }
+  __syncthreads();
+  double dmax0 = 0.0;
+  int rank = n;
+  const int row_l = tid >> 2, part = tid & 3;
+  for (int k = 0; k < n; ++k) {
+    // ---- pivot: argmax of the residual diagonal over positions >= k
+    {
+      double v = -1.0e300; int idx = n;
+      for (int i = k + tid; i < n; i += nt) {
+        const double di = s_d[i];
+        if (di > v || (di == v && i < idx)) { v = di; idx = i; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
+      if ((tid & 63) == 0) { s_redv[tid >> 6] = v; s_redi[tid >> 6] = idx; }
+      __syncthreads();
+      if (tid == 0) {
+        double bv = s_redv[0]; int bi = s_redi[0];
+        for (int w = 1; w < (nt >> 6); ++w)
+          if (s_redv[w] > bv || (s_redv[w] == bv && s_redi[w] < bi)) { bv = s_redv[w]; bi = s_redi[w]; }
+        s_ctl[0] = bi;
+        s_redv[0] = bv;
+      }
+      __syncthreads();
+    }
+    const int p = s_ctl[0];
+    const double pval = s_redv[0];
+    if (k == 0) dmax0 = pval;
+    if (!(pval > tol * dmax0) || !(pval > 0.0)) { rank = k; break; }
+    // ---- symmetric swap of positions k and p inside the packed triangle
+    if (p != k) {
+      for (int e = tid; e < n; e += nt) {
+        if (e < k) {                         // row segments left of column k (already factor columns)
+          const double t = X[tri(k, e)]; X[tri(k, e)] = X[tri(p, e)]; X[tri(p, e)] = t;
+        } else if (e > k && e < p) {         // column k below the diagonal <-> row p
+          const double t = X[tri(e, k)]; X[tri(e, k)] = X[tri(p, e)]; X[tri(p, e)] = t;
+        } else if (e > p) {                  // columns k and p below row p
+          const double t = X[tri(e, k)]; X[tri(e, k)] = X[tri(e, p)]; X[tri(e, p)] = t;
+        } else if (e == k) {                 // diagonal entries, bookkeeping
+          const double t = X[tri(k, k)]; X[tri(k, k)] = X[tri(p, p)]; X[tri(p, p)] = t;
+          const double td = s_d[k]; s_d[k] = s_d[p]; s_d[p] = td;
+          const int tp = s_perm[k]; s_perm[k] = s_perm[p]; s_perm[p] = tp;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- column k: v_i = A[i,k] - sum_{j<k} L[i,j] L[k,j]   (i >= k), 4 lanes per row
+    double vloc = 0.0;
+    const int i = k + row_l;
+    if (i < n) {
+      const double* xi = X + tri(i, 0);
+      const double* xk = X + tri(k, 0);
+      double acc = 0.0;
+      for (int j = part; j < k; j += 4) acc = fma(xi[j], xk[j], acc);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      vloc = xi[k] - acc;
+    }
+    if (i == k && part == 0) s_redv[1] = vloc;               // v_k
+    __syncthreads();
+    const double lkk = sqrt(fmax(s_redv[1], 0.0));
+    if (i < n && part == 0) {
+      const double col = (i == k) ? lkk : vloc / lkk;
+      X[tri(i, k)] = col;
+      s_d[i] -= col * col;
+    }
+    __syncthreads();
+  }
+  // ---- scatter to the caller's layout (rows in ORIGINAL order, column-major by step)
+  for (int e = tid; e < n * n; e += nt) {
+    const int k = e / n, i = e - k * n;                       // step k, position i
+    const double v = (i >= k && k < rank) ? X[tri(i, k)] : 0.0;
+    const int r = s_perm[i];
+    Lw[(size_t)k * n + r] = v;
+    W0[(size_t)k * ld + r] = (float)v;
+  }
+  for (int e = tid; e < n * (ld - n); e += nt) {
+    const int k = e / (ld - n), r = n + (e - k * (ld - n));
+    W0[(size_t)k * ld + r] = 0.f;
+  }
+  for (int i = tid; i < n; i += nt) piv[i] = s_perm[i];
+  if (tid == 0) rank_all[blockIdx.x] = rank;
+}
+
 __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ a_all, int n,
                                                      double tol, float* __restrict__ w0_all, int ld,
                                                      double* __restrict__ lw_all,
@@ -150,8 +269,15 @@ extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, flo
   if (batch <= 0) return BASD_OK;
   if (n < 1 || n > 256 || ld < n || ld > 256 + 64)
     return fail(BASD_ERR_SHAPE, "pchol_f64: bad shape n=%d ld=%d", n, ld);
-  hipLaunchKernelGGL(pchol_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, a, n, tol, w0,
-                     ld, lwork, piv, rank);
+  const size_t lds = ((size_t)n * (n + 1) / 2 + n + 16) * 8 + ((size_t)n + 16 + 2) * 4 + 64;
+  if (lds <= 160 * 1024 && n <= 192) {
+    hipFuncSetAttribute((const void*)pchol_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(pchol_lds_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, a, n, tol, w0, ld,
+                       lwork, piv, rank);
+  } else {   // global-memory (L2-resident) fallback for 192 < n <= 256
+    hipLaunchKernelGGL(pchol_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, a, n, tol, w0,
+                       ld, lwork, piv, rank);
+  }
   return check_launch("pchol_f64");
 }
 
