@@ -59,6 +59,13 @@ int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in,
                     const float* proj, int d_out,
                     double* gram, double* colsum, void* stream);
 
+/* bf16-input fast path of basd_token_gram: x [rows, d_in] bf16, proj_split [3, d_out, d_in] bf16 =
+ * the three-term bf16 split of the fp32 projection (P = Ph + Pm + Pl, each term the bf16
+ * rounding of the remainder).  Same outputs / zeroing contract.  d_out in {32, 64, 128, 192},
+ * d_in % 32 == 0. */
+int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, const void* proj_split, int d_out,
+                           double* gram, double* colsum, void* stream);
+
 /* Pivoted (diagonal pivoting) Cholesky of `batch` symmetric PSD fp64 matrices
  * a[b] (n x n).  Writes
  *   w0   [batch, n, ld] fp32: column k (contiguous, ld floats) = k-th Cholesky column,
@@ -121,12 +128,14 @@ int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int L, int E,
 /* Batched GEMM with fp64 accumulation on the fp64 matrix cores: C[b] = op(A[b]) op(B[b]).
  * Row-major, explicit leading dimensions and batch strides (in elements); A/B dtype F32 or F64,
  * C dtype F32 or F64; trans_x != 0 means the stored matrix is the transpose of op(X).
+ * symmetric != 0 (M == N, result known symmetric, e.g. X X^T): only the lower 64x64 tiles are
+ * computed and mirrored on store.
  * Replaces the torch.bmm / matmul calls of the Procrustes core that must not round to fp32
  * (reference src/losses/relational.py:47 forms the cross-covariance in fp32). */
 int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int trans_a,
                    const void* b, int b_dtype, int64_t b_stride, int ldb, int trans_b,
                    void* c, int c_dtype, int64_t c_stride, int ldc,
-                   int batch, int M, int N, int K, void* stream);
+                   int batch, int M, int N, int K, int symmetric, void* stream);
 
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:

@@ -136,7 +136,7 @@ def lerp_(y, z, w):
     y.add_(z - y, alpha=w)
 
 
-def bgemm_f64(a, b, *, trans_a=False, trans_b=False, out_dtype=torch.float64):
+def bgemm_f64(a, b, *, trans_a=False, trans_b=False, out_dtype=torch.float64, symmetric=False):
     a, b = a.double(), b.double()
     if trans_a:
         a = a.transpose(1, 2)

@@ -204,3 +204,12 @@ def test_trinv_matches_triangular_solve(nat, n, rank):
         assert torch.allclose(x[:rank, :rank] @ lp, torch.eye(rank, dtype=torch.float64), atol=1e-9)
         assert float(x[rank:].abs().max()) == 0.0 if rank < n else True
         assert float(torch.triu(x[:rank, :rank], 1).abs().max()) == 0.0
+
+
+def test_bgemm_f64_symmetric_mode(nat):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 150, 70, generator=g, dtype=torch.float64)
+    c = nat.bgemm_f64(x.cuda(), x.cuda(), trans_b=True, symmetric=True).cpu()
+    ref = x @ x.transpose(1, 2)
+    assert torch.allclose(c, ref, rtol=0, atol=1e-12 * float(ref.abs().max()))
+    assert torch.equal(c, c.transpose(1, 2))

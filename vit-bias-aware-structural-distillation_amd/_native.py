@@ -19,7 +19,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F64 = 0, 1, 2
 JACOBI_LDS_BYTES = 163840
 
 EXPORTS = (
-    "basd_version", "basd_last_error", "basd_token_gram", "basd_pchol_f64", "basd_jacobi_svd",
+    "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64",
 )
@@ -95,6 +95,26 @@ def jacobi_ld(m_rows: int) -> int:
 
 
 # --------------------------------------------------------------------------- #
+_SPLIT_CACHE: dict = {}
+
+
+def split_bf16x3(proj: torch.Tensor) -> torch.Tensor:
+    """fp32 [d_out, d_in] -> bf16 [3, d_out, d_in] with proj == hi + mid + lo to 2^-24 (cached per buffer)."""
+    key = (proj.data_ptr(), proj._version, tuple(proj.shape))
+    hit = _SPLIT_CACHE.get(key)
+    if hit is None:
+        p = proj.detach().float()
+        hi = p.bfloat16()
+        r1 = p - hi.float()
+        mid = r1.bfloat16()
+        lo = (r1 - mid.float()).bfloat16()
+        hit = torch.stack([hi, mid, lo]).contiguous()
+        if len(_SPLIT_CACHE) > 16:
+            _SPLIT_CACHE.clear()
+        _SPLIT_CACHE[key] = hit
+    return hit
+
+
 def token_gram(x: torch.Tensor, proj: torch.Tensor):
     """x [M, d_in] (f32/bf16), proj [d_out, d_in] f32 -> gram [d_out, d_out] f64, colsum [d_out] f64."""
     _need_cuda(x, proj)
@@ -104,6 +124,11 @@ def token_gram(x: torch.Tensor, proj: torch.Tensor):
     d_out = proj.shape[0]
     gram = torch.zeros(d_out, d_out, dtype=torch.float64, device=x.device)
     colsum = torch.zeros(d_out, dtype=torch.float64, device=x.device)
+    if x.dtype == torch.bfloat16 and d_out in (32, 64, 128, 192) and d_in % 32 == 0:
+        ps = split_bf16x3(proj)
+        _check(lib().basd_token_gram_bf16x3(_ptr(x), ctypes.c_int64(m), d_in, _ptr(ps), d_out, _ptr(gram),
+                                            _ptr(colsum), _stream()), "basd_token_gram_bf16x3")
+        return gram, colsum
     _check(lib().basd_token_gram(_ptr(x), _dtype_code(x), ctypes.c_int64(m), d_in, _ptr(proj), d_out,
                                  _ptr(gram), _ptr(colsum), _stream()), "basd_token_gram")
     return gram, colsum
@@ -234,7 +259,7 @@ def lerp_(y, z, w: float) -> None:
 
 
 def bgemm_f64(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
-              out_dtype=torch.float64) -> torch.Tensor:
+              out_dtype=torch.float64, symmetric: bool = False) -> torch.Tensor:
     """Batched op(a) @ op(b) with fp64 accumulation; a, b [batch, r, c] fp32/fp64 contiguous."""
     _need_cuda(a, b)
     a, b = a.contiguous(), b.contiguous()
@@ -247,7 +272,8 @@ def bgemm_f64(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_
     i64 = ctypes.c_int64
     _check(lib().basd_bgemm_f64(_ptr(a), code[a.dtype], i64(a.shape[1] * a.shape[2]), a.shape[2], int(trans_a),
                                 _ptr(b), code[b.dtype], i64(b.shape[1] * b.shape[2]), b.shape[2], int(trans_b),
-                                _ptr(c), code[out_dtype], i64(M * N), N, batch, M, N, K, _stream()), "basd_bgemm_f64")
+                                _ptr(c), code[out_dtype], i64(M * N), N, batch, M, N, K, int(symmetric), _stream()),
+           "basd_bgemm_f64")
     return c
 
 

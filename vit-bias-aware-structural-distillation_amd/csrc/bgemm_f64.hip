@@ -49,11 +49,12 @@ template <typename TA, typename TB, typename TC>
 __global__ __launch_bounds__(256) void bgemm_f64_kernel(const TA* __restrict__ a, int64_t sa, int lda, int ta,
                                                         const TB* __restrict__ b, int64_t sb, int ldb, int tb,
                                                         TC* __restrict__ c, int64_t sc, int ldc, int M, int N,
-                                                        int K) {
+                                                        int K, int sym) {
   __shared__ double As[BK * BLD];
   __shared__ double Bs[BK * BLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  if (sym && n0 > m0) return;   // C = X X^T: lower tiles only, mirrored on store
   const TA* A = a + (size_t)blockIdx.z * sa;
   const TB* B = b + (size_t)blockIdx.z * sb;
   TC* C = c + (size_t)blockIdx.z * sc;
@@ -94,29 +95,33 @@ __global__ __launch_bounds__(256) void bgemm_f64_kernel(const TA* __restrict__ a
       for (int reg = 0; reg < 4; ++reg) {
         const int r = m0 + wm + i * 16 + (lane >> 4) + 4 * reg;
         const int col = n0 + wn + j * 16 + (lane & 15);
-        if (r < M && col < N) C[(size_t)r * ldc + col] = (TC)acc[i][j][reg];
+        if (r < M && col < N) {
+          C[(size_t)r * ldc + col] = (TC)acc[i][j][reg];
+          if (sym && n0 != m0) C[(size_t)col * ldc + r] = (TC)acc[i][j][reg];
+        }
       }
 }
 
 template <typename TA, typename TB, typename TC>
 static void launch_bgemm(const void* a, int64_t sa, int lda, int ta, const void* b, int64_t sb, int ldb, int tb,
-                         void* c, int64_t sc, int ldc, int batch, int M, int N, int K, hipStream_t st) {
+                         void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, hipStream_t st) {
   dim3 grid((N + BT - 1) / BT, (M + BT - 1) / BT, batch);
   hipLaunchKernelGGL((bgemm_f64_kernel<TA, TB, TC>), grid, dim3(256), 0, st, (const TA*)a, sa, lda, ta,
-                     (const TB*)b, sb, ldb, tb, (TC*)c, sc, ldc, M, N, K);
+                     (const TB*)b, sb, ldb, tb, (TC*)c, sc, ldc, M, N, K, sym);
 }
 
 }  // namespace basd
 
 extern "C" int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int trans_a, const void* b,
                               int b_dtype, int64_t b_stride, int ldb, int trans_b, void* c, int c_dtype,
-                              int64_t c_stride, int ldc, int batch, int M, int N, int K, void* stream) {
+                              int64_t c_stride, int ldc, int batch, int M, int N, int K, int symmetric, void* stream) {
   using namespace basd;
   if (batch <= 0 || M <= 0 || N <= 0) return BASD_OK;
+  if (symmetric && M != N) return fail(BASD_ERR_SHAPE, "bgemm_f64: symmetric needs M == N");
   if (K <= 0 || batch > 65535) return fail(BASD_ERR_SHAPE, "bgemm_f64: bad shape batch=%d K=%d", batch, K);
   hipStream_t st = (hipStream_t)stream;
   const int key = a_dtype * 100 + b_dtype * 10 + c_dtype;
-#define BASD_BG(TA, TB, TC) launch_bgemm<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, st)
+#define BASD_BG(TA, TB, TC) launch_bgemm<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, st)
   switch (key) {
     case 2: BASD_BG(float, float, double); break;      // f32 x f32 -> f64
     case 0: BASD_BG(float, float, float); break;

@@ -171,3 +171,161 @@ extern "C" int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_i
 #undef BASD_TG_LAUNCH
   return check_launch("token_gram");
 }
+
+// --------------------------------------------------------------------------------------------
+// bf16-input fast path.  The tokens a ViT emits under bf16 autocast are EXACT bf16 values; the
+// fp32 projection P is split into three bf16 terms P = Ph + Pm + Pl (24 significant bits), so
+//     z = X Ph + X Pm + X Pl
+// is evaluated with bf16 MFMAs (v_mfma_f32_16x16x32_bf16, exact products, fp32 accumulate) at
+// 16x the fp32-MFMA rate for 3x the instructions.  Same accuracy class as the fp32 path
+// (|dP/P| <= 2^-24), checked against fp64 in tests/test_kernels_gpu.py.
+//
+// Workgroup = 256 threads = 4 waves (1 wave per SIMD: the whole 512-register file), tile =
+// 128 rows (32 per wave).  Per K chunk of 32 the three P splits are staged once in LDS
+// ([split][col][32 k], 80-byte rows) and every B fragment read serves two row groups.  The z
+// tile then goes to LDS (overlaying the P buffer) for the fp64 Gram MFMAs, whose accumulators
+// (20 lower-triangular tiles per wave) persist in registers across all the tiles of a workgroup.
+namespace basd {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int TM2 = 128;          // rows per workgroup tile
+constexpr int KC2 = 32;           // K chunk
+constexpr int PROW = 80;          // bytes per (split, col) row of the staged P chunk (64 + 16 pad)
+
+template <int NCT>   // NCT = d_out / 16 (12 for d_out = 192)
+__global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned short* __restrict__ x, int64_t rows,
+                                                                int d_in, const unsigned short* __restrict__ psplit,
+                                                                double* __restrict__ gram,
+                                                                double* __restrict__ colsum) {
+  constexpr int D_OUT = NCT * 16;
+  constexpr int LDZ = D_OUT + 16;
+  constexpr int NGT = NCT * (NCT + 1) / 2;
+  constexpr int GT_PER_WAVE = (NGT + 3) / 4;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* Pl = smem;                                   // [3][D_OUT][PROW] bytes   (projection phase)
+  float* Z = reinterpret_cast<float*>(smem);                  // [TM2][LDZ] floats        (Gram phase)
+  __shared__ unsigned char s_it[NGT], s_jt[NGT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int g = tid; g < NGT; g += 256) {
+    int it = 0;
+    while ((it + 1) * (it + 2) / 2 <= g) ++it;
+    s_it[g] = (unsigned char)it;
+    s_jt[g] = (unsigned char)(g - it * (it + 1) / 2);
+  }
+  f64x4 gacc[GT_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < GT_PER_WAVE; ++i) gacc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  double csum = 0.0;
+  const size_t split_stride = (size_t)D_OUT * d_in;
+
+  const int64_t ntiles = (rows + TM2 - 1) / TM2;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * TM2 + wave * 32;
+    f32x4 zacc[2][NCT];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) zacc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t ra = r0 + (lane & 15), rb = ra + 16;
+    const unsigned short* xa = x + ra * d_in + 8 * (lane >> 4);
+    const unsigned short* xb = x + rb * d_in + 8 * (lane >> 4);
+    for (int k0 = 0; k0 < d_in; k0 += KC2) {
+      __syncthreads();                       // previous chunk's fragment reads (or the Gram phase) are done
+      // stage the three P splits of this K chunk: 3 * D_OUT rows of 64 bytes
+      for (int e = tid; e < 3 * D_OUT * 4; e += 256) {
+        const int q = e & 3, rc = e >> 2;    // rc = split * D_OUT + col
+        const int s = rc / D_OUT, col = rc - s * D_OUT;
+        const uint4 v = *reinterpret_cast<const uint4*>(psplit + s * split_stride + (size_t)col * d_in + k0 + 8 * q);
+        *reinterpret_cast<uint4*>(Pl + (size_t)rc * PROW + 16 * q) = v;
+      }
+      bf16x8 a0 = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+      if (ra < rows) a0 = *reinterpret_cast<const bf16x8*>(xa + k0);
+      if (rb < rows) a1 = *reinterpret_cast<const bf16x8*>(xb + k0);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(
+              Pl + (size_t)(s * D_OUT + c * 16 + (lane & 15)) * PROW + 16 * (lane >> 4));
+          zacc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, zacc[0][c], 0, 0, 0);
+          zacc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, zacc[1][c], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                          // all fragment reads done before Z overlays the P buffer
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          Z[(wave * 32 + g * 16 + (lane >> 4) * 4 + reg) * LDZ + c * 16 + (lane & 15)] = zacc[g][c][reg];
+    __syncthreads();
+    if (tid < D_OUT) {
+      double s = 0.0;
+      for (int r = 0; r < TM2; ++r) s += (double)Z[r * LDZ + tid];
+      csum += s;
+    }
+#pragma unroll
+    for (int gi = 0; gi < GT_PER_WAVE; ++gi) {
+      const int g = wave + gi * 4;
+      if (g < NGT) {
+        const int it = s_it[g], jt = s_jt[g];
+#pragma unroll 4
+        for (int kk = 0; kk < TM2 / 4; ++kk) {
+          const float* zr = Z + (kk * 4 + (lane >> 4)) * LDZ + (lane & 15);
+          gacc[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)zr[it * 16], (double)zr[jt * 16], gacc[gi], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int gi = 0; gi < GT_PER_WAVE; ++gi) {
+    const int g = wave + gi * 4;
+    if (g < NGT) {
+      const int it = s_it[g], jt = s_jt[g];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = it * 16 + (lane >> 4) + 4 * reg;
+        const int j = jt * 16 + (lane & 15);
+        const double v = gacc[gi][reg];
+        atomicAdd(&gram[(size_t)i * D_OUT + j], v);
+        if (it != jt) atomicAdd(&gram[(size_t)j * D_OUT + i], v);
+      }
+    }
+  }
+  if (tid < D_OUT) atomicAdd(&colsum[tid], csum);
+}
+
+template <int NCT>
+static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, const void* psplit, double* gram, double* colsum,
+                             hipStream_t st) {
+  constexpr int D_OUT = NCT * 16;
+  const size_t p_bytes = (size_t)3 * D_OUT * PROW;
+  const size_t z_bytes = (size_t)TM2 * (D_OUT + 16) * 4;
+  const size_t lds = p_bytes > z_bytes ? p_bytes : z_bytes;
+  const int64_t ntiles = (rows + TM2 - 1) / TM2;
+  const int grid = (int)(ntiles < 256 ? ntiles : 256);
+  hipFuncSetAttribute((const void*)token_gram_bf16x3_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((token_gram_bf16x3_kernel<NCT>), dim3(grid), dim3(256), lds, st, (const unsigned short*)x, rows,
+                     d_in, (const unsigned short*)psplit, gram, colsum);
+}
+
+}  // namespace basd
+
+extern "C" int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, const void* proj_split, int d_out,
+                                      double* gram, double* colsum, void* stream) {
+  using namespace basd;
+  if (rows <= 0) return BASD_OK;
+  if (d_in % KC2 || d_in < KC2) return fail(BASD_ERR_SHAPE, "token_gram_bf16x3: d_in %% 32 != 0 (%d)", d_in);
+  hipStream_t st = (hipStream_t)stream;
+  switch (d_out) {
+    case 32: launch_tg_bf16x3<2>(x, rows, d_in, proj_split, gram, colsum, st); break;
+    case 64: launch_tg_bf16x3<4>(x, rows, d_in, proj_split, gram, colsum, st); break;
+    case 128: launch_tg_bf16x3<8>(x, rows, d_in, proj_split, gram, colsum, st); break;
+    case 192: launch_tg_bf16x3<12>(x, rows, d_in, proj_split, gram, colsum, st); break;
+    default: return fail(BASD_ERR_SHAPE, "token_gram_bf16x3: d_out %d not in {32, 64, 128, 192}", d_out);
+  }
+  return check_launch("token_gram_bf16x3");
+}

@@ -220,8 +220,7 @@ def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
     if not ops.jacobi_fits(d_s, d_s):
         raise BasdShapeError(f"Procrustes core {d_s}x{d_s} does not fit the LDS-resident Jacobi")
     cross = ops.bgemm_f64(s_w, t_w, trans_a=True)                       # [B, D_s, D_t] fp64
-    mx = ops.bgemm_f64(cross, cross, trans_b=True)
-    mx = 0.5 * (mx + mx.transpose(1, 2))
+    mx = ops.bgemm_f64(cross, cross, trans_b=True, symmetric=True)     # exactly symmetric by construction
     w0, lwork, piv, rank = ops.pchol(mx, PCHOL_TOL)
     sigma, _ = ops.jacobi_svd(w0, d_s)                                  # w0[:, i, :d_s] = sigma_i u_i
     l_inv = ops.trinv(lwork, piv, rank)                                 # L_p^-1 P  [B, k, r] fp64

@@ -72,7 +72,9 @@ class Attention(nn.Module):
         """Head-averaged token importance [B, N]: the only part of softmax(QK^T/sqrt(hd)) the
         loss reads (src/losses/relational.py:22-27; teacher.py:33-37 builds the full map)."""
         if has_cls:
-            logits = (q[:, :, :1].float() @ k.float().transpose(-2, -1)) * self.scale   # [B,H,1,T]
+            # q_cls k^T in the activation dtype (bf16 in, fp32 accumulate) like the reference's
+            # autocast matmul (teacher.py:36), softmax in fp32; no fp32 copy of K
+            logits = (q[:, :, :1] @ k.transpose(-2, -1)).float() * self.scale               # [B,H,1,T]
             return logits.softmax(dim=-1)[:, :, 0, 1:].mean(dim=1)
         attn = ((q.float() @ k.float().transpose(-2, -1)) * self.scale).softmax(dim=-1)
         return attn.mean(dim=(1, 2))
