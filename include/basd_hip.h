@@ -93,10 +93,14 @@ int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank,
  * [A; I] input pass the row count of A so that the bottom block -- the
  * accumulated right singular vectors -- is excluded from the norm).
  * sweeps [batch] (optional, may be NULL) receives the sweeps used.
+ * active (optional, device int32 [batch], may be NULL): matrix b has non-zero entries only in its
+ * leading active[b] columns (and rows, if active_rows != 0); the sweeps then run over that
+ * block only (rank-masked principal-angle problems, no host sync on the ranks).
  * Requires n_cols <= 256, ld % 4 == 0, n_cols * ld * 4 + 4096 <= 160 KiB. */
 int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
                     float tol, int max_sweeps, int sort,
-                    float* sigma, int32_t* sweeps, void* stream);
+                    float* sigma, int32_t* sweeps, const int32_t* active, int active_rows,
+                    void* stream);
 
 /* Marchenko-Pastur rank on device (no host sync).  evals [batch, n] (any order),
  * rows = M of the [M, D] token matrix, d = D; uses the min(M, D) largest eigenvalues,

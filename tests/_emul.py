@@ -63,7 +63,7 @@ def pchol(a, tol=1e-13):
     return w0, lwork, piv, rank
 
 
-def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True):
+def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True, active=None, active_rows=False):
     batch, n_cols, ld = w.shape
     if norm_rows is None:
         norm_rows = m_rows

@@ -213,3 +213,22 @@ def test_bgemm_f64_symmetric_mode(nat):
     ref = x @ x.transpose(1, 2)
     assert torch.allclose(c, ref, rtol=0, atol=1e-12 * float(ref.abs().max()))
     assert torch.equal(c, c.transpose(1, 2))
+
+
+def test_jacobi_active_block_matches_full_run(nat):
+    """rank-masked input: sweeping only the leading active block gives the same singular values."""
+    g = torch.Generator().manual_seed(5)
+    n, ks = 64, [5, 17, 40, 64]
+    a = torch.zeros(len(ks), n, n)
+    for b, k in enumerate(ks):
+        a[b, :k, :k] = torch.randn(k, k, generator=g)
+    ld = nat.jacobi_ld(n)
+    w1 = _colmajor(a.cuda(), ld)
+    w2 = w1.clone()
+    s1, _ = nat.jacobi_svd(w1, n)
+    s2, sw = nat.jacobi_svd(w2, n, active=torch.tensor(ks, dtype=torch.int32, device="cuda"), active_rows=True)
+    ref = torch.linalg.svdvals(a.double())
+    assert torch.allclose(s2.cpu().double(), ref, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(s1, s2, rtol=2e-5, atol=1e-6)
+    for b, k in enumerate(ks):            # columns beyond the block stay exactly zero
+        assert float(s2[b, k:].abs().max()) == 0.0 if k < n else True

@@ -150,7 +150,8 @@ def pchol(a: torch.Tensor, tol: float = 1e-13):
 
 
 def jacobi_svd(w: torch.Tensor, m_rows: int, norm_rows: int | None = None, *, tol: float | None = None,
-               max_sweeps: int = 40, sort: bool = True):
+               max_sweeps: int = 40, sort: bool = True, active: torch.Tensor | None = None,
+               active_rows: bool = False):
     """In-place one-sided Jacobi on w [batch, n_cols, ld] (column-major matrices).
 
     Returns (sigma [batch, n_cols], sweeps [batch]); w's columns become sigma_c * u_c.
@@ -165,7 +166,9 @@ def jacobi_svd(w: torch.Tensor, m_rows: int, norm_rows: int | None = None, *, to
     sigma = torch.empty(batch, n_cols, dtype=torch.float32, device=w.device)
     sweeps = torch.empty(batch, dtype=torch.int32, device=w.device)
     _check(lib().basd_jacobi_svd(_ptr(w), batch, m_rows, n_cols, ld, norm_rows, ctypes.c_float(tol),
-                                 max_sweeps, int(sort), _ptr(sigma), _ptr(sweeps), _stream()),
+                                 max_sweeps, int(sort), _ptr(sigma), _ptr(sweeps),
+                                 _ptr(None if active is None else active.contiguous().int()), int(active_rows),
+                                 _stream()),
            "basd_jacobi_svd")
     return sigma, sweeps
 

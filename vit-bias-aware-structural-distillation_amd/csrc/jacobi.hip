@@ -17,7 +17,8 @@ namespace basd {
 template <int MAXCH>
 __global__ __launch_bounds__(1024) void jacobi_kernel(
     float* __restrict__ wg, int m, int n, int ld, int norm_rows, float tol,
-    int max_sweeps, int sort, float* __restrict__ sigma, int32_t* __restrict__ sweeps_out) {
+    int max_sweeps, int sort, float* __restrict__ sigma, int32_t* __restrict__ sweeps_out,
+    const int32_t* __restrict__ active, int active_rows) {
   extern __shared__ __align__(16) float lds[];
   float* W = lds;
   const int tid = threadIdx.x;
@@ -34,8 +35,14 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
   __syncthreads();
 
   // rows m..ld-1 are zero padding (kept zero by any rotation): never loaded / rotated / stored
-  const int mrows = (m + 3) & ~3;
-  const int n_even = n + (n & 1);
+  // `active` (optional, per matrix): only the leading n_act columns (and, with active_rows, rows)
+  // are non-zero -- the rank-masked principal-angle blocks.  The tournament then runs over n_act
+  // columns only; the remaining (zero) columns and rows are left untouched.
+  int n_act = n;
+  if (active) { n_act = active[blockIdx.x]; n_act = n_act < 2 ? 2 : (n_act > n ? n : n_act); }
+  int mrows = (m + 3) & ~3;
+  if (active && active_rows) { const int ma = (n_act + 3) & ~3; mrows = ma < mrows ? ma : mrows; }
+  const int n_even = n_act + (n_act & 1);
   const int R = n_even - 1;
   const int npairs = n_even >> 1;
   const int g = tid >> 3, sub = tid & 7;
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
       int p, q;
       if (g == 0) { p = R; q = t; }
       else { p = t + g; if (p >= R) p -= R; q = t - g; if (q < 0) q += R; }
-      if (has_pair && p < n && q < n) {
+      if (has_pair && p < n_act && q < n_act) {
         float* cp = W + (size_t)p * ld + sub * 4;
         float* cq = W + (size_t)q * ld + sub * 4;
         float4 a[MAXCH], b[MAXCH];
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
 
 extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
                                float tol, int max_sweeps, int sort, float* sigma,
-                               int32_t* sweeps, void* stream) {
+                               int32_t* sweeps, const int32_t* active, int active_rows, void* stream) {
   using namespace basd;
   if (batch <= 0) return BASD_OK;
   if (n_cols < 1 || n_cols > BASD_JACOBI_MAX_COLS || ld % 4 != 0 || m_rows > ld || m_rows < 1 ||
@@ -164,7 +171,8 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     hipFuncSetAttribute((const void*)jacobi_kernel<MC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                         (int)lds_bytes);                                                           \
     hipLaunchKernelGGL(jacobi_kernel<MC>, dim3(batch), dim3(threads), lds_bytes, st, w, m_rows,    \
-                       n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps);               \
+                       n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active,       \
+                       active_rows);                                                              \
   } while (0)
   if (chunks <= 2) BASD_LAUNCH_JACOBI(2);
   else if (chunks <= 4) BASD_LAUNCH_JACOBI(4);

@@ -120,7 +120,8 @@ class _SelectorWeightsFn(torch.autograd.Function):
         ld = ops.jacobi_ld(D)
         w = torch.zeros(E * L, D, ld, device=dev, dtype=torch.float32)
         w[:, :, :D] = a_bar.reshape(E * L, D, D).transpose(1, 2)    # column c contiguous
-        sig, _ = ops.jacobi_svd(w, D)                               # cosines, descending
+        # only the leading k_j x k_j block of pair (i, j) is non-zero: sweep just that block
+        sig, _ = ops.jacobi_svd(w, D, active=ranks.repeat(E), active_rows=True)   # cosines, descending
         sig = sig.view(E, L, D)
         u_s = torch.where(sig.unsqueeze(-1) > 1e-20, w[:, :, :D].view(E, L, D, D) / sig.clamp_min(1e-20).unsqueeze(-1),
                           torch.zeros(1, device=dev))               # [E, L, m, b]
