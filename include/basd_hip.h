@@ -22,6 +22,7 @@
  *   basd_mix_tokens        layer_selector.py:110-112 (+ torch.stack :128-129 eliminated)
  *   basd_procrustes_prep   src/losses/relational.py:29-46, src/losses/combined.py:9-14
  *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
+ *   basd_wgrad_bf16        autograd of the student's timm nn.Linear layers (trainer.py:157)
  *   basd_sf_adamw_step     schedulefree.AdamWScheduleFree.step  src/training/trainer.py:54-58,158
  */
 #ifndef BASD_HIP_H
@@ -140,6 +141,13 @@ int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int tr
                    const void* b, int b_dtype, int64_t b_stride, int ldb, int trans_b,
                    void* c, int c_dtype, int64_t c_stride, int ldc,
                    int batch, int M, int N, int K, int symmetric, void* stream);
+
+/* ViT weight-gradient GEMM (backward of nn.Linear): dw[n][k] += sum_m dy[m][n] x[m][k],
+ * db[n] += sum_m dy[m][n] (db may be NULL).  dy [M, N], x [M, K] bf16 row-major, dw [N, K] /
+ * db [N] fp32, ACCUMULATED with atomics (caller zero-initialises or accumulates on purpose).
+ * N % 64 == 0, K % 64 == 0. */
+int basd_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, float* dw, float* db,
+                    void* stream);
 
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:

@@ -159,3 +159,12 @@ def trinv(lwork, piv, rank):
         x[r:] = 0.0
         out[b][:, pv] = x
     return out
+
+
+def wgrad_supported(n, k):
+    return n % 64 == 0 and k % 64 == 0 and n >= 64 and k >= 64
+
+
+def wgrad_bf16(dy, x, need_bias=True):
+    dw = dy.float().t() @ x.float()
+    return dw, (dy.float().sum(0) if need_bias else None)

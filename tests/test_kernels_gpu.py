@@ -232,3 +232,41 @@ def test_jacobi_active_block_matches_full_run(nat):
     assert torch.allclose(s1, s2, rtol=2e-5, atol=1e-6)
     for b, k in enumerate(ks):            # columns beyond the block stay exactly zero
         assert float(s2[b, k:].abs().max()) == 0.0 if k < n else True
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 576, 192), (1000, 192, 768), (333, 64, 64), (4096, 768, 192), (777, 128, 128)])
+def test_wgrad_bf16(nat, M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    dy = (torch.randn(M, N, generator=g) * 0.1).bfloat16()
+    x = torch.randn(M, K, generator=g).bfloat16()
+    dw, db = nat.wgrad_bf16(dy.cuda(), x.cuda())
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    scale = float((dy.double().abs().t() @ x.double().abs()).max())
+    assert torch.allclose(dw.cpu().double(), ref_w, rtol=0, atol=3e-6 * scale)
+    assert torch.allclose(db.cpu().double(), ref_b, rtol=0, atol=3e-6 * float(dy.double().abs().sum(0).max()))
+
+
+def test_basd_linear_matches_nn_linear_backward():
+    from basd_amd.models.linear import BasdLinear
+    torch.manual_seed(0)
+    lin = BasdLinear(192, 576).cuda()
+    ref = torch.nn.Linear(192, 576).cuda()
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(8, 197, 192, device="cuda", requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = lin(x)
+        y2 = ref(x2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    y2.backward(gy)
+    torch.testing.assert_close(y, y2, atol=0, rtol=0)
+    torch.testing.assert_close(lin.weight.grad, ref.weight.grad, atol=2e-2, rtol=2e-2)   # ref accumulates to bf16
+    torch.testing.assert_close(lin.bias.grad, ref.bias.grad, atol=5e-2, rtol=2e-2)
+    torch.testing.assert_close(x.grad, x2.grad, atol=1e-3, rtol=1e-2)
+    # against an fp64 reference the fp32-accumulated kernel is the more accurate of the two
+    w_true = gy.bfloat16().double().reshape(-1, 576).t() @ x.detach().bfloat16().double().reshape(-1, 192)
+    err_mine = float((lin.weight.grad.double() - w_true).norm() / w_true.norm())
+    err_ref = float((ref.weight.grad.double() - w_true).norm() / w_true.norm())
+    assert err_mine < 1e-5 and err_mine <= err_ref

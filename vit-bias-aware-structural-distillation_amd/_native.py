@@ -21,7 +21,7 @@ JACOBI_LDS_BYTES = 163840
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
-    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64",
+    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16",
 )
 
 
@@ -288,3 +288,21 @@ def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor) -> torch.T
     _check(lib().basd_trinv_f64(_ptr(lwork.contiguous()), _ptr(piv.contiguous()), _ptr(rank.contiguous()), batch, n,
                                 _ptr(out), _stream()), "basd_trinv_f64")
     return out
+
+
+def wgrad_supported(n: int, k: int) -> bool:
+    return n % 64 == 0 and k % 64 == 0 and n >= 64 and k >= 64
+
+
+def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True):
+    """dy [M, N], x [M, K] bf16 -> (dw [N, K] fp32, db [N] fp32 | None)."""
+    _need_cuda(dy, x)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+    dy, x = dy.contiguous(), x.contiguous()
+    m, n = dy.shape
+    k = x.shape[1]
+    dw = torch.zeros(n, k, dtype=torch.float32, device=dy.device)
+    db = torch.zeros(n, dtype=torch.float32, device=dy.device) if need_bias else None
+    _check(lib().basd_wgrad_bf16(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _stream()),
+           "basd_wgrad_bf16")
+    return dw, db

@@ -26,6 +26,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
+from .linear import BasdLinear
+
 
 class DropPath(nn.Module):
     def __init__(self, p: float = 0.0):
@@ -55,8 +57,8 @@ class Attention(nn.Module):
         self.num_heads = num_heads
         self.head_dim = dim // num_heads
         self.scale = self.head_dim ** -0.5
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
-        self.proj = nn.Linear(dim, dim)
+        self.qkv = BasdLinear(dim, dim * 3, bias=qkv_bias)
+        self.proj = BasdLinear(dim, dim)
         self.tap: dict | None = None       # set by the teacher tap: {"has_cls": bool, "out": tensor}
 
     def forward(self, x):
@@ -83,9 +85,9 @@ class Attention(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, dim: int, hidden: int):
         super().__init__()
-        self.fc1 = nn.Linear(dim, hidden)
+        self.fc1 = BasdLinear(dim, hidden)
         self.act = nn.GELU()
-        self.fc2 = nn.Linear(hidden, dim)
+        self.fc2 = BasdLinear(hidden, dim)
 
     def forward(self, x):
         return self.fc2(self.act(self.fc1(x)))
