@@ -107,8 +107,8 @@ def main():
     trainer.optimizer.train()
     trainer.model.train()
 
-    timer = KernelTimer(native, ["jacobi_svd", "pchol", "token_gram", "mix_tokens", "mix_grad_dots",
-                                 "procrustes_prep", "sf_adamw_step", "mp_rank"])
+    timer = KernelTimer(native, ["jacobi_svd", "pchol", "trinv", "bgemm_f64", "token_gram", "mix_tokens",
+                                 "mix_grad_dots", "procrustes_prep", "wgrad_bf16", "sf_adamw_step", "mp_rank"])
     timer.install()
 
     for i in range(args.warmup):
@@ -178,6 +178,7 @@ def main():
                          "tflops_if_whole_step": vit_flops / (ms_per_step / 1e3) / 1e12, "peak_bf16": 2500.0},
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in ks.items()},
             "loss": float(loss),
+            "teacher_ranks": list(trainer.basd_loss.layer_selector.subspace_ranks.values()),
         }
         print(json.dumps(line))
     if world > 1:

@@ -55,8 +55,13 @@ const char* basd_last_error(void);
 /* z = X P^T (fp32 MFMA), gram = z^T z and colsum = 1^T z accumulated in fp64.
  * x: [rows, d_in] row-major (dtype code), proj: [d_out, d_in] fp32 row-major,
  * gram: [d_out, d_out] fp64 (MUST be zeroed by the caller), colsum: [d_out] fp64 (zeroed).
- * d_out <= 256 and d_out % 16 == 0; d_in % 16 == 0. */
+ * d_out <= 256 and d_out % 16 == 0; d_in % 32 == 0.
+ * Strided token views: logical row r is token r % rows_per_batch of batch r / rows_per_batch and
+ * lives at x + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * d_in (elements); a
+ * contiguous matrix is rows_per_batch = rows, batch_stride = 0.  This is how the CLS-stripped view
+ * out[:, 1:, :] of a block output is consumed without a copy. */
 int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in,
+                    int rows_per_batch, int64_t batch_stride,
                     const float* proj, int d_out,
                     double* gram, double* colsum, void* stream);
 
@@ -64,8 +69,8 @@ int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in,
  * the three-term bf16 split of the fp32 projection (P = Ph + Pm + Pl, each term the bf16
  * rounding of the remainder).  Same outputs / zeroing contract.  d_out in {32, 64, 128, 192},
  * d_in % 32 == 0. */
-int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, const void* proj_split, int d_out,
-                           double* gram, double* colsum, void* stream);
+int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_batch, int64_t batch_stride,
+                           const void* proj_split, int d_out, double* gram, double* colsum, void* stream);
 
 /* Pivoted (diagonal pivoting) Cholesky of `batch` symmetric PSD fp64 matrices
  * a[b] (n x n).  Writes
@@ -111,16 +116,19 @@ int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int 
 
 /* mixed[i] = sum_j w[i, j] * x_j   (all E mixes from ONE pass over the teacher layers)
  * x_layers: device array of L pointers to [elems] tensors (dtype code), w: [E, L] fp32,
- * out: [E, elems] fp32. */
+ * out: [E, elems] fp32 (contiguous).  Each source layer is a batch-strided view: logical element e
+ * is at layer + (e / per_batch) * batch_stride + e % per_batch (contiguous: per_batch = elems). */
 int basd_mix_tokens(const void* const* x_layers, int x_dtype, int L, int E,
-                    const float* w, int64_t elems, float* out, void* stream);
+                    const float* w, int64_t elems, int64_t per_batch, int64_t batch_stride,
+                    float* out, void* stream);
 
 /* Procrustes prep for `batch` = B samples of one extraction point:
- * s [B, N_s, D_s] (dtype), t [B, N_t, D_t] fp32 (mixed teacher), imp [B, N_t] fp32.
+ * s [B, N_s, D_s] (dtype; sample b at s + b * s_batch_stride), t [B, N_t, D_t] fp32 (mixed teacher),
+ * imp [B, N_t] fp32.
  * Resamples t and imp to N_s (2-tap linear, align_corners=False), normalises imp,
  * weighted-centres and sqrt-weights:
  *   s_w [B, N_s, D_s], t_w [B, N_s, D_t] fp32, a [B, N_s], tr [B, 2] = (tr_s, tr_t). */
-int basd_procrustes_prep(const void* s, int s_dtype, const float* t, const float* imp,
+int basd_procrustes_prep(const void* s, int s_dtype, int64_t s_batch_stride, const float* t, const float* imp,
                          int B, int N_s, int N_t, int D_s, int D_t,
                          float* s_w, float* t_w, float* a, float* tr, void* stream);
 
@@ -128,7 +136,8 @@ int basd_procrustes_prep(const void* s, int s_dtype, const float* t, const float
  * g: [E, elems] fp32, dots: [E, L] fp64 (MUST be zeroed by the caller; fp64 atomics keep the
  * result independent of the arrival order to ~1e-16). */
 int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int L, int E,
-                       const float* g, int64_t elems, double* dots, void* stream);
+                       const float* g, int64_t elems, int64_t per_batch, int64_t batch_stride,
+                       double* dots, void* stream);
 
 /* Batched GEMM with fp64 accumulation on the fp64 matrix cores: C[b] = op(A[b]) op(B[b]).
  * Row-major, explicit leading dimensions and batch strides (in elements); A/B dtype F32 or F64,

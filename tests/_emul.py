@@ -23,6 +23,7 @@ def jacobi_fits(n_cols: int, m_rows: int) -> bool:
 
 
 def token_gram(x, proj):
+    x = x.reshape(-1, x.shape[-1])
     z = (x.float() @ proj.float().t()).double()
     return z.t() @ z, z.sum(0)
 

@@ -270,3 +270,26 @@ def test_basd_linear_matches_nn_linear_backward():
     err_mine = float((lin.weight.grad.double() - w_true).norm() / w_true.norm())
     err_ref = float((ref.weight.grad.double() - w_true).norm() / w_true.norm())
     assert err_mine < 1e-5 and err_mine <= err_ref
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batch_strided_views_are_consumed_without_copy(nat, dtype):
+    """out[:, 1:, :] views (CLS stripped) through token_gram / mix / dots / prep == contiguous copies."""
+    g = torch.Generator().manual_seed(9)
+    B, T, D = 5, 41, 64
+    blocks = [torch.randn(B, T, D, generator=g).to(dtype).cuda() for _ in range(3)]
+    views = [b[:, 1:, :] for b in blocks]
+    dense = [v.contiguous() for v in views]
+    p = torch.linalg.qr(torch.randn(D, 32, generator=g))[0].T.contiguous().cuda()
+    g1, c1 = nat.token_gram(views[0], p)
+    g2, c2 = nat.token_gram(dense[0].reshape(-1, D), p)
+    torch.testing.assert_close(g1, g2, rtol=1e-12, atol=1e-9)
+    torch.testing.assert_close(c1, c2, rtol=1e-12, atol=1e-9)
+    w = torch.softmax(torch.randn(2, 3, generator=g), 1).cuda()
+    torch.testing.assert_close(nat.mix_tokens(views, w), nat.mix_tokens(dense, w), rtol=0, atol=0)
+    gr = torch.randn(2, B, T - 1, D, generator=g).cuda()
+    torch.testing.assert_close(nat.mix_grad_dots(views, gr), nat.mix_grad_dots(dense, gr), rtol=1e-12, atol=1e-9)
+    t = torch.randn(B, T - 1, 96, generator=g).cuda()
+    imp = (torch.rand(B, T - 1, generator=g) + 0.1).cuda()
+    for a, b in zip(nat.procrustes_prep(views[1], t, imp), nat.procrustes_prep(dense[1], t, imp)):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)

@@ -115,21 +115,35 @@ def split_bf16x3(proj: torch.Tensor) -> torch.Tensor:
     return hit
 
 
-def token_gram(x: torch.Tensor, proj: torch.Tensor):
-    """x [M, d_in] (f32/bf16), proj [d_out, d_in] f32 -> gram [d_out, d_out] f64, colsum [d_out] f64."""
-    _need_cuda(x, proj)
+def _token_view(x: torch.Tensor):
+    """[B, N, D] (possibly a batch-strided view such as out[:, 1:, :]) or [M, D] ->
+    (tensor to take the pointer from, rows, d, rows_per_batch, batch_stride) without copying when possible."""
+    if x.dim() == 3:
+        b, n, d = x.shape
+        if x.stride(2) == 1 and x.stride(1) == d and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
+            return x, b * n, d, n, x.stride(0)
+        x = x.contiguous()
+        return x, b * n, d, n, n * d
     x = x.contiguous()
+    return x, x.shape[0], x.shape[1], x.shape[0], 0
+
+
+def token_gram(x: torch.Tensor, proj: torch.Tensor):
+    """x [M, d_in] or [B, N, d_in] view (f32/bf16), proj [d_out, d_in] f32 ->
+    gram [d_out, d_out] f64, colsum [d_out] f64."""
+    _need_cuda(x, proj)
+    x, m, d_in, rpb, bstride = _token_view(x)
     proj = proj.contiguous().float()
-    m, d_in = x.shape
     d_out = proj.shape[0]
     gram = torch.zeros(d_out, d_out, dtype=torch.float64, device=x.device)
     colsum = torch.zeros(d_out, dtype=torch.float64, device=x.device)
+    i64 = ctypes.c_int64
     if x.dtype == torch.bfloat16 and d_out in (32, 64, 128, 192) and d_in % 32 == 0:
         ps = split_bf16x3(proj)
-        _check(lib().basd_token_gram_bf16x3(_ptr(x), ctypes.c_int64(m), d_in, _ptr(ps), d_out, _ptr(gram),
+        _check(lib().basd_token_gram_bf16x3(_ptr(x), i64(m), d_in, rpb, i64(bstride), _ptr(ps), d_out, _ptr(gram),
                                             _ptr(colsum), _stream()), "basd_token_gram_bf16x3")
         return gram, colsum
-    _check(lib().basd_token_gram(_ptr(x), _dtype_code(x), ctypes.c_int64(m), d_in, _ptr(proj), d_out,
+    _check(lib().basd_token_gram(_ptr(x), _dtype_code(x), i64(m), d_in, rpb, i64(bstride), _ptr(proj), d_out,
                                  _ptr(gram), _ptr(colsum), _stream()), "basd_token_gram")
     return gram, colsum
 
@@ -192,41 +206,58 @@ def _ptr_table(layers: list[torch.Tensor]) -> torch.Tensor:
     return torch.tensor([t.data_ptr() for t in layers], dtype=torch.int64, device=layers[0].device)
 
 
+def _layer_views(layers):
+    """Common (per_batch, batch_stride) of same-shape layers; copies only layers that are not
+    dense-per-sample views."""
+    shape = layers[0].shape
+    assert all(t.shape == shape and t.dtype == layers[0].dtype for t in layers)
+    per_batch = layers[0][0].numel()
+    def dense_per_sample(t):
+        return t[0].is_contiguous() and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+    strides = {t.stride(0) for t in layers}
+    if len(strides) == 1 and all(dense_per_sample(t) for t in layers):
+        return list(layers), per_batch, layers[0].stride(0)
+    return [t.contiguous() for t in layers], per_batch, per_batch
+
+
 def mix_tokens(layers: list[torch.Tensor], w: torch.Tensor) -> torch.Tensor:
-    """layers: L tensors of identical shape/dtype; w [E, L] f32 -> out [E, *shape] f32."""
+    """layers: L same-shape [B, ...] tensors (batch-strided views allowed); w [E, L] f32 -> [E, *shape] f32."""
     _need_cuda(*layers, w)
-    layers = [t.contiguous() for t in layers]
     code = _dtype_code(layers[0])
-    assert all(t.shape == layers[0].shape and t.dtype == layers[0].dtype for t in layers)
+    layers, per_batch, bstride = _layer_views(layers)
     E, L = w.shape
     assert L == len(layers)
     elems = layers[0].numel()
     out = torch.empty((E,) + tuple(layers[0].shape), dtype=torch.float32, device=w.device)
     table = _ptr_table(layers)
-    _check(lib().basd_mix_tokens(_ptr(table), code, L, E, _ptr(w.contiguous().float()),
-                                 ctypes.c_int64(elems), _ptr(out), _stream()), "basd_mix_tokens")
+    i64 = ctypes.c_int64
+    _check(lib().basd_mix_tokens(_ptr(table), code, L, E, _ptr(w.contiguous().float()), i64(elems), i64(per_batch),
+                                 i64(bstride), _ptr(out), _stream()), "basd_mix_tokens")
     return out
 
 
 def mix_grad_dots(layers: list[torch.Tensor], g: torch.Tensor) -> torch.Tensor:
     """dots[i, j] = <g[i], layers[j]>; g [E, *shape] f32 -> [E, L] f64."""
     _need_cuda(*layers, g)
-    layers = [t.contiguous() for t in layers]
     code = _dtype_code(layers[0])
+    layers, per_batch, bstride = _layer_views(layers)
     E, L = g.shape[0], len(layers)
     elems = layers[0].numel()
     assert g.numel() == E * elems and g.dtype == torch.float32
     dots = torch.zeros(E, L, dtype=torch.float64, device=g.device)
     table = _ptr_table(layers)
-    _check(lib().basd_mix_grad_dots(_ptr(table), code, L, E, _ptr(g.contiguous()), ctypes.c_int64(elems),
-                                    _ptr(dots), _stream()), "basd_mix_grad_dots")
+    i64 = ctypes.c_int64
+    _check(lib().basd_mix_grad_dots(_ptr(table), code, L, E, _ptr(g.contiguous()), i64(elems), i64(per_batch),
+                                    i64(bstride), _ptr(dots), _stream()), "basd_mix_grad_dots")
     return dots
 
 
 def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor):
-    """s [B,N_s,D_s] (f32/bf16), t [B,N_t,D_t] f32, imp [B,N_t] f32 -> s_w, t_w, a, tr[B,2]."""
+    """s [B,N_s,D_s] (f32/bf16, batch-strided view allowed), t [B,N_t,D_t] f32, imp [B,N_t] f32
+    -> s_w, t_w, a, tr[B,2]."""
     _need_cuda(s, t, imp)
-    s = s.contiguous()
+    if not (s[0].is_contiguous() and s.data_ptr() % 16 == 0):
+        s = s.contiguous()
     t = t.contiguous().float()
     imp = imp.contiguous().float()
     B, N_s, D_s = s.shape
@@ -236,8 +267,8 @@ def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor):
     t_w = torch.empty(B, N_s, D_t, dtype=torch.float32, device=dev)
     a = torch.empty(B, N_s, dtype=torch.float32, device=dev)
     tr = torch.empty(B, 2, dtype=torch.float32, device=dev)
-    _check(lib().basd_procrustes_prep(_ptr(s), _dtype_code(s), _ptr(t), _ptr(imp), B, N_s, N_t, D_s, D_t,
-                                      _ptr(s_w), _ptr(t_w), _ptr(a), _ptr(tr), _stream()),
+    _check(lib().basd_procrustes_prep(_ptr(s), _dtype_code(s), ctypes.c_int64(s.stride(0)), _ptr(t), _ptr(imp), B, N_s,
+                                      N_t, D_s, D_t, _ptr(s_w), _ptr(t_w), _ptr(a), _ptr(tr), _stream()),
            "basd_procrustes_prep")
     return s_w, t_w, a, tr
 

@@ -37,7 +37,8 @@ template <> struct Vec<unsigned short> {   // bf16 bits
 template <typename T, int E>
 __global__ __launch_bounds__(256) void mix_tokens_kernel(const T* const* __restrict__ layers, int L,
                                                          const float* __restrict__ w, int64_t nvec,
-                                                         float* __restrict__ out, int64_t elems) {
+                                                         float* __restrict__ out, int64_t elems,
+                                                         int64_t per_batch, int64_t batch_stride) {
   constexpr int N = Vec<T>::N;
   __shared__ float s_w[kMaxE * kMaxL];
   __shared__ const T* s_ptr[kMaxL];
@@ -51,9 +52,12 @@ __global__ __launch_bounds__(256) void mix_tokens_kernel(const T* const* __restr
     for (int i = 0; i < E; ++i)
 #pragma unroll
       for (int k = 0; k < N; ++k) acc[i][k] = 0.f;
+    // element v*N of the logical contiguous tensor inside a batch-strided source view
+    const int64_t e0 = v * N, sb = e0 / per_batch;
+    const int64_t src_off = sb * batch_stride + (e0 - sb * per_batch);
     for (int j = 0; j < L; ++j) {
       float x[N];
-      Vec<T>::load(s_ptr[j] + v * N, x);
+      Vec<T>::load(s_ptr[j] + src_off, x);
 #pragma unroll
       for (int i = 0; i < E; ++i) {
         const float wij = s_w[i * L + j];
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(256) void mix_tokens_kernel(const T* const* __restr
 template <typename T, int E>
 __global__ __launch_bounds__(256) void mix_grad_dots_kernel(const T* const* __restrict__ layers, int L,
                                                             const float* __restrict__ g, int64_t nvec,
-                                                            int64_t elems, double* __restrict__ dots) {
+                                                            int64_t elems, double* __restrict__ dots,
+                                                            int64_t per_batch, int64_t batch_stride) {
   constexpr int N = Vec<T>::N;
   __shared__ const T* s_ptr[kMaxL];
   __shared__ double s_acc[kMaxE * kMaxL];
@@ -91,6 +96,8 @@ __global__ __launch_bounds__(256) void mix_grad_dots_kernel(const T* const* __re
       for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
          v += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t e0 = v * N, sb = e0 / per_batch;
+      const int64_t src_off = sb * batch_stride + (e0 - sb * per_batch);
       float gv[E][N];
 #pragma unroll
       for (int i = 0; i < E; ++i) {
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void mix_grad_dots_kernel(const T* const* __re
       for (int j = 0; j < 16; ++j) {
         if (j < jn) {
           float x[N];
-          Vec<T>::load(s_ptr[j0 + j] + v * N, x);
+          Vec<T>::load(s_ptr[j0 + j] + src_off, x);
 #pragma unroll
           for (int i = 0; i < E; ++i) {
             float d = 0.f;
@@ -134,8 +141,8 @@ __global__ __launch_bounds__(256) void mix_grad_dots_kernel(const T* const* __re
 template <typename TS>
 __global__ __launch_bounds__(512) void procrustes_prep_kernel(
     const TS* __restrict__ s_all, const float* __restrict__ t_all, const float* __restrict__ imp_all,
-    int N_s, int N_t, int D_s, int D_t, float* __restrict__ sw_all, float* __restrict__ tw_all,
-    float* __restrict__ a_all, float* __restrict__ tr_all) {
+    int N_s, int N_t, int D_s, int D_t, int64_t s_batch_stride, float* __restrict__ sw_all,
+    float* __restrict__ tw_all, float* __restrict__ a_all, float* __restrict__ tr_all) {
   extern __shared__ __align__(16) float sm[];
   float* s_a = sm;                 // [N_s] normalised importance
   int* s_lo = reinterpret_cast<int*>(s_a + N_s);   // [N_s]
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(512) void procrustes_prep_kernel(
   float* s_mu = s_fr + N_s;        // [D_s + D_t]
   float* s_red = s_mu + D_s + D_t; // [32]
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const TS* s = s_all + (size_t)b * N_s * D_s;
+  const TS* s = s_all + (size_t)b * s_batch_stride;
   const float* t = t_all + (size_t)b * N_t * D_t;
   const float* imp = imp_all + (size_t)b * N_t;
   float* sw = sw_all + (size_t)b * N_s * D_s;
@@ -252,45 +259,45 @@ namespace basd {
 
 template <typename T, int E>
 static void launch_mix(const void* const* layers, int L, const float* w, int64_t nvec, float* out,
-                       int64_t elems, hipStream_t st) {
+                       int64_t elems, int64_t pb, int64_t bs, hipStream_t st) {
   hipLaunchKernelGGL((mix_tokens_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st,
-                     (const T* const*)layers, L, w, nvec, out, elems);
+                     (const T* const*)layers, L, w, nvec, out, elems, pb, bs);
 }
 template <typename T, int E>
 static void launch_dots(const void* const* layers, int L, const float* g, int64_t nvec, int64_t elems,
-                        double* dots, hipStream_t st) {
+                        double* dots, int64_t pb, int64_t bs, hipStream_t st) {
   hipLaunchKernelGGL((mix_grad_dots_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st,
-                     (const T* const*)layers, L, g, nvec, elems, dots);
+                     (const T* const*)layers, L, g, nvec, elems, dots, pb, bs);
 }
 
 template <typename T>
 static int dispatch_mix(int E, const void* const* layers, int L, const float* w, int64_t nvec, float* out,
-                        int64_t elems, hipStream_t st) {
+                        int64_t elems, int64_t pb, int64_t bs, hipStream_t st) {
   switch (E) {
-    case 1: launch_mix<T, 1>(layers, L, w, nvec, out, elems, st); break;
-    case 2: launch_mix<T, 2>(layers, L, w, nvec, out, elems, st); break;
-    case 3: launch_mix<T, 3>(layers, L, w, nvec, out, elems, st); break;
-    case 4: launch_mix<T, 4>(layers, L, w, nvec, out, elems, st); break;
-    case 5: launch_mix<T, 5>(layers, L, w, nvec, out, elems, st); break;
-    case 6: launch_mix<T, 6>(layers, L, w, nvec, out, elems, st); break;
-    case 7: launch_mix<T, 7>(layers, L, w, nvec, out, elems, st); break;
-    case 8: launch_mix<T, 8>(layers, L, w, nvec, out, elems, st); break;
+    case 1: launch_mix<T, 1>(layers, L, w, nvec, out, elems, pb, bs, st); break;
+    case 2: launch_mix<T, 2>(layers, L, w, nvec, out, elems, pb, bs, st); break;
+    case 3: launch_mix<T, 3>(layers, L, w, nvec, out, elems, pb, bs, st); break;
+    case 4: launch_mix<T, 4>(layers, L, w, nvec, out, elems, pb, bs, st); break;
+    case 5: launch_mix<T, 5>(layers, L, w, nvec, out, elems, pb, bs, st); break;
+    case 6: launch_mix<T, 6>(layers, L, w, nvec, out, elems, pb, bs, st); break;
+    case 7: launch_mix<T, 7>(layers, L, w, nvec, out, elems, pb, bs, st); break;
+    case 8: launch_mix<T, 8>(layers, L, w, nvec, out, elems, pb, bs, st); break;
     default: return fail(BASD_ERR_SHAPE, "E=%d out of 1..8", E);
   }
   return BASD_OK;
 }
 template <typename T>
 static int dispatch_dots(int E, const void* const* layers, int L, const float* g, int64_t nvec,
-                         int64_t elems, double* dots, hipStream_t st) {
+                         int64_t elems, double* dots, int64_t pb, int64_t bs, hipStream_t st) {
   switch (E) {
-    case 1: launch_dots<T, 1>(layers, L, g, nvec, elems, dots, st); break;
-    case 2: launch_dots<T, 2>(layers, L, g, nvec, elems, dots, st); break;
-    case 3: launch_dots<T, 3>(layers, L, g, nvec, elems, dots, st); break;
-    case 4: launch_dots<T, 4>(layers, L, g, nvec, elems, dots, st); break;
-    case 5: launch_dots<T, 5>(layers, L, g, nvec, elems, dots, st); break;
-    case 6: launch_dots<T, 6>(layers, L, g, nvec, elems, dots, st); break;
-    case 7: launch_dots<T, 7>(layers, L, g, nvec, elems, dots, st); break;
-    case 8: launch_dots<T, 8>(layers, L, g, nvec, elems, dots, st); break;
+    case 1: launch_dots<T, 1>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
+    case 2: launch_dots<T, 2>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
+    case 3: launch_dots<T, 3>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
+    case 4: launch_dots<T, 4>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
+    case 5: launch_dots<T, 5>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
+    case 6: launch_dots<T, 6>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
+    case 7: launch_dots<T, 7>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
+    case 8: launch_dots<T, 8>(layers, L, g, nvec, elems, dots, pb, bs, st); break;
     default: return fail(BASD_ERR_SHAPE, "E=%d out of 1..8", E);
   }
   return BASD_OK;
@@ -299,17 +306,19 @@ static int dispatch_dots(int E, const void* const* layers, int L, const float* g
 }  // namespace basd
 
 extern "C" int basd_mix_tokens(const void* const* x_layers, int x_dtype, int L, int E, const float* w,
-                               int64_t elems, float* out, void* stream) {
+                               int64_t elems, int64_t per_batch, int64_t batch_stride, float* out, void* stream) {
   using namespace basd;
   if (L < 1 || L > kMaxL) return fail(BASD_ERR_SHAPE, "mix_tokens: L=%d out of 1..%d", L, kMaxL);
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (x_dtype == BASD_DTYPE_F32) {
     if (elems % 4) return fail(BASD_ERR_SHAPE, "mix_tokens: elems %% 4 != 0");
-    rc = dispatch_mix<float>(E, x_layers, L, w, elems / 4, out, elems, st);
+    if (per_batch % 4) return fail(BASD_ERR_SHAPE, "mix_tokens: per_batch %% 4 != 0");
+    rc = dispatch_mix<float>(E, x_layers, L, w, elems / 4, out, elems, per_batch, batch_stride, st);
   } else if (x_dtype == BASD_DTYPE_BF16) {
     if (elems % 8) return fail(BASD_ERR_SHAPE, "mix_tokens: elems %% 8 != 0");
-    rc = dispatch_mix<unsigned short>(E, x_layers, L, w, elems / 8, out, elems, st);
+    if (per_batch % 8 || batch_stride % 8) return fail(BASD_ERR_SHAPE, "mix_tokens: per_batch / batch_stride %% 8 != 0");
+    rc = dispatch_mix<unsigned short>(E, x_layers, L, w, elems / 8, out, elems, per_batch, batch_stride, st);
   } else {
     return fail(BASD_ERR_DTYPE, "mix_tokens: dtype %d", x_dtype);
   }
@@ -318,17 +327,20 @@ extern "C" int basd_mix_tokens(const void* const* x_layers, int x_dtype, int L, 
 }
 
 extern "C" int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int L, int E, const float* g,
-                                  int64_t elems, double* dots, void* stream) {
+                                  int64_t elems, int64_t per_batch, int64_t batch_stride, double* dots,
+                                  void* stream) {
   using namespace basd;
   if (L < 1 || L > kMaxL) return fail(BASD_ERR_SHAPE, "mix_grad_dots: L=%d out of 1..%d", L, kMaxL);
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (x_dtype == BASD_DTYPE_F32) {
     if (elems % 4) return fail(BASD_ERR_SHAPE, "mix_grad_dots: elems %% 4 != 0");
-    rc = dispatch_dots<float>(E, x_layers, L, g, elems / 4, elems, dots, st);
+    if (per_batch % 4) return fail(BASD_ERR_SHAPE, "mix_grad_dots: per_batch %% 4 != 0");
+    rc = dispatch_dots<float>(E, x_layers, L, g, elems / 4, elems, dots, per_batch, batch_stride, st);
   } else if (x_dtype == BASD_DTYPE_BF16) {
     if (elems % 8) return fail(BASD_ERR_SHAPE, "mix_grad_dots: elems %% 8 != 0");
-    rc = dispatch_dots<unsigned short>(E, x_layers, L, g, elems / 8, elems, dots, st);
+    if (per_batch % 8 || batch_stride % 8) return fail(BASD_ERR_SHAPE, "mix_grad_dots: per_batch / batch_stride %% 8 != 0");
+    rc = dispatch_dots<unsigned short>(E, x_layers, L, g, elems / 8, elems, dots, per_batch, batch_stride, st);
   } else {
     return fail(BASD_ERR_DTYPE, "mix_grad_dots: dtype %d", x_dtype);
   }
@@ -336,9 +348,9 @@ extern "C" int basd_mix_grad_dots(const void* const* x_layers, int x_dtype, int 
   return check_launch("mix_grad_dots");
 }
 
-extern "C" int basd_procrustes_prep(const void* s, int s_dtype, const float* t, const float* imp, int B,
-                                    int N_s, int N_t, int D_s, int D_t, float* s_w, float* t_w,
-                                    float* a, float* tr, void* stream) {
+extern "C" int basd_procrustes_prep(const void* s, int s_dtype, int64_t s_batch_stride, const float* t,
+                                    const float* imp, int B, int N_s, int N_t, int D_s, int D_t, float* s_w,
+                                    float* t_w, float* a, float* tr, void* stream) {
   using namespace basd;
   if (B <= 0) return BASD_OK;
   if (N_s < 1 || N_t < 1 || D_s < 1 || D_t < 1)
@@ -348,10 +360,10 @@ extern "C" int basd_procrustes_prep(const void* s, int s_dtype, const float* t, 
   hipStream_t st = (hipStream_t)stream;
   if (s_dtype == BASD_DTYPE_F32) {
     hipLaunchKernelGGL(procrustes_prep_kernel<float>, dim3(B), dim3(512), lds, st, (const float*)s, t, imp,
-                       N_s, N_t, D_s, D_t, s_w, t_w, a, tr);
+                       N_s, N_t, D_s, D_t, s_batch_stride, s_w, t_w, a, tr);
   } else if (s_dtype == BASD_DTYPE_BF16) {
     hipLaunchKernelGGL(procrustes_prep_kernel<unsigned short>, dim3(B), dim3(512), lds, st,
-                       (const unsigned short*)s, t, imp, N_s, N_t, D_s, D_t, s_w, t_w, a, tr);
+                       (const unsigned short*)s, t, imp, N_s, N_t, D_s, D_t, s_batch_stride, s_w, t_w, a, tr);
   } else {
     return fail(BASD_ERR_DTYPE, "procrustes_prep: dtype %d", s_dtype);
   }

@@ -30,6 +30,7 @@ template <> __device__ __forceinline__ float ld_as_f32<unsigned short>(const uns
 
 template <typename T, int MAXGT>   // MAXGT = Gram tiles per wave: 10 (d_out <= 192) or 17 (<= 256)
 __global__ __launch_bounds__(512) void token_gram_kernel(const T* __restrict__ x, int64_t rows, int d_in,
+                                                         int rows_per_batch, int64_t batch_stride,
                                                          const float* __restrict__ proj, int d_out,
                                                          double* __restrict__ gram,
                                                          double* __restrict__ colsum) {
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(512) void token_gram_kernel(const T* __restrict__ x
       for (int i = tid; i < TM * KC; i += 512) {
         const int r = i / KC, k = i - r * KC;
         const int64_t gr = r0 + r;
-        Xs[r * XS + k] = (gr < rows) ? ld_as_f32<T>(x + gr * d_in + k0 + k) : 0.f;
+        // row gr of the logical [rows, d_in] matrix lives at batch gr / N, token gr % N of a strided view
+        const int64_t gb = gr / rows_per_batch;
+        Xs[r * XS + k] = (gr < rows) ? ld_as_f32<T>(x + gb * batch_stride + (gr - gb * rows_per_batch) * d_in + k0 + k) : 0.f;
       }
       for (int i = tid; i < d_out * KC; i += 512) {
         const int r = i / KC, k = i - r * KC;
@@ -144,10 +147,12 @@ __global__ __launch_bounds__(512) void token_gram_kernel(const T* __restrict__ x
 
 }  // namespace basd
 
-extern "C" int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in, const float* proj,
-                               int d_out, double* gram, double* colsum, void* stream) {
+extern "C" int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in, int rows_per_batch,
+                               int64_t batch_stride, const float* proj, int d_out, double* gram, double* colsum,
+                               void* stream) {
   using namespace basd;
   if (rows <= 0) return BASD_OK;
+  if (rows_per_batch < 1) return fail(BASD_ERR_SHAPE, "token_gram: rows_per_batch < 1");
   if (d_out < 16 || d_out > 256 || d_out % 16 || d_in < KC || d_in % KC)
     return fail(BASD_ERR_SHAPE, "token_gram: need d_out %% 16 == 0, 16 <= d_out <= 256, d_in %% %d == 0 (got %d, %d)",
                 KC, d_out, d_in);
@@ -159,7 +164,7 @@ extern "C" int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_i
   do {                                                                                              \
     hipFuncSetAttribute((const void*)token_gram_kernel<T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((token_gram_kernel<T, G>), dim3(grid), dim3(512), lds, st, (const T*)x, rows, d_in, \
-                       proj, d_out, gram, colsum);                                                  \
+                       rows_per_batch, batch_stride, proj, d_out, gram, colsum);                                                  \
   } while (0)
   if (x_dtype == BASD_DTYPE_F32) {
     if (d_out <= 192) BASD_TG_LAUNCH(float, 10); else BASD_TG_LAUNCH(float, 17);
@@ -194,7 +199,8 @@ constexpr int PROW = 80;          // bytes per (split, col) row of the staged P 
 
 template <int NCT>   // NCT = d_out / 16 (12 for d_out = 192)
 __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned short* __restrict__ x, int64_t rows,
-                                                                int d_in, const unsigned short* __restrict__ psplit,
+                                                                int d_in, int rows_per_batch, int64_t batch_stride,
+                                                                const unsigned short* __restrict__ psplit,
                                                                 double* __restrict__ gram,
                                                                 double* __restrict__ colsum) {
   constexpr int D_OUT = NCT * 16;
@@ -227,8 +233,9 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
 #pragma unroll
       for (int c = 0; c < NCT; ++c) zacc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int64_t ra = r0 + (lane & 15), rb = ra + 16;
-    const unsigned short* xa = x + ra * d_in + 8 * (lane >> 4);
-    const unsigned short* xb = x + rb * d_in + 8 * (lane >> 4);
+    const int64_t ba = ra / rows_per_batch, bb = rb / rows_per_batch;      // strided [B, N, D] views
+    const unsigned short* xa = x + ba * batch_stride + (ra - ba * rows_per_batch) * d_in + 8 * (lane >> 4);
+    const unsigned short* xb = x + bb * batch_stride + (rb - bb * rows_per_batch) * d_in + 8 * (lane >> 4);
     for (int k0 = 0; k0 < d_in; k0 += KC2) {
       __syncthreads();                       // previous chunk's fragment reads (or the Gram phase) are done
       // stage the three P splits of this K chunk: 3 * D_OUT rows of 64 bytes
@@ -299,8 +306,8 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
 }
 
 template <int NCT>
-static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, const void* psplit, double* gram, double* colsum,
-                             hipStream_t st) {
+static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_batch, int64_t batch_stride,
+                             const void* psplit, double* gram, double* colsum, hipStream_t st) {
   constexpr int D_OUT = NCT * 16;
   const size_t p_bytes = (size_t)3 * D_OUT * PROW;
   const size_t z_bytes = (size_t)TM2 * (D_OUT + 16) * 4;
@@ -309,22 +316,24 @@ static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, const void* 
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
   hipFuncSetAttribute((const void*)token_gram_bf16x3_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((token_gram_bf16x3_kernel<NCT>), dim3(grid), dim3(256), lds, st, (const unsigned short*)x, rows,
-                     d_in, (const unsigned short*)psplit, gram, colsum);
+                     d_in, rows_per_batch, batch_stride, (const unsigned short*)psplit, gram, colsum);
 }
 
 }  // namespace basd
 
-extern "C" int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, const void* proj_split, int d_out,
-                                      double* gram, double* colsum, void* stream) {
+extern "C" int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_batch, int64_t batch_stride,
+                                      const void* proj_split, int d_out, double* gram, double* colsum,
+                                      void* stream) {
   using namespace basd;
   if (rows <= 0) return BASD_OK;
+  if (rows_per_batch < 1) return fail(BASD_ERR_SHAPE, "token_gram_bf16x3: rows_per_batch < 1");
   if (d_in % KC2 || d_in < KC2) return fail(BASD_ERR_SHAPE, "token_gram_bf16x3: d_in %% 32 != 0 (%d)", d_in);
   hipStream_t st = (hipStream_t)stream;
   switch (d_out) {
-    case 32: launch_tg_bf16x3<2>(x, rows, d_in, proj_split, gram, colsum, st); break;
-    case 64: launch_tg_bf16x3<4>(x, rows, d_in, proj_split, gram, colsum, st); break;
-    case 128: launch_tg_bf16x3<8>(x, rows, d_in, proj_split, gram, colsum, st); break;
-    case 192: launch_tg_bf16x3<12>(x, rows, d_in, proj_split, gram, colsum, st); break;
+    case 32: launch_tg_bf16x3<2>(x, rows, d_in, rows_per_batch, batch_stride, proj_split, gram, colsum, st); break;
+    case 64: launch_tg_bf16x3<4>(x, rows, d_in, rows_per_batch, batch_stride, proj_split, gram, colsum, st); break;
+    case 128: launch_tg_bf16x3<8>(x, rows, d_in, rows_per_batch, batch_stride, proj_split, gram, colsum, st); break;
+    case 192: launch_tg_bf16x3<12>(x, rows, d_in, rows_per_batch, batch_stride, proj_split, gram, colsum, st); break;
     default: return fail(BASD_ERR_SHAPE, "token_gram_bf16x3: d_out %d not in {32, 64, 128, 192}", d_out);
   }
   return check_launch("token_gram_bf16x3");

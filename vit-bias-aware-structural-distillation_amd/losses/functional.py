@@ -97,13 +97,13 @@ class _SelectorWeightsFn(torch.autograd.Function):
         m_t = teacher[0].shape[0] * teacher[0].shape[1]
         cen_t = []
         for x in teacher:                               # layer_selector.py:71-73, :134-136
-            g, c = ops.token_gram(x.reshape(-1, x.shape[-1]), proj_t)
+            g, c = ops.token_gram(x, proj_t)             # [B, N, D] view, no copy
             mats.append(g)
             cen_t.append(g - torch.outer(c, c) / m_t)
         mats.extend(cen_t)
         m_s = student[0].shape[0] * student[0].shape[1]
         for s in student:                               # layer_selector.py:84-92
-            g, c = ops.token_gram(s.reshape(-1, s.shape[-1]), proj_s)
+            g, c = ops.token_gram(s, proj_s)
             mats.append(g - torch.outer(c, c) / m_s)
         sigma, u, _ = psd_eig(torch.stack(mats))
         ranks = ops.mp_rank(sigma[:L] ** 2, m_t, D, D - 1)          # int32 [L], stays on device
@@ -170,15 +170,15 @@ class _SelectorWeightsFn(torch.autograd.Function):
             s = student[i]
             # centring z = s P^T over rows == centring s (linear map), so d loss / d s = (s - mean) W
             centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
-            grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).view_as(s).to(s.dtype))
+            grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
         n_teacher = len(ctx.needs_input_grad) - 4 - E
         return (g_lt, None, None, None, *grads, *([None] * n_teacher))
 
 
 def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_temperatures):
     """-> (weights [E, L] with grad, ranks int32 [L] on device, pre_softmax [E, L])."""
-    student = [t.contiguous() for t in student_tokens]
-    teacher = [t.detach().contiguous() for t in teacher_tokens]
+    student = list(student_tokens)          # batch-strided views (CLS-stripped block outputs) are consumed in place
+    teacher = [t.detach() for t in teacher_tokens]
     return _SelectorWeightsFn.apply(log_temperatures, proj_s, proj_t, len(student), *student, *teacher)
 
 
@@ -201,7 +201,7 @@ class _MixFn(torch.autograd.Function):
 
 def mix_layers(w: torch.Tensor, layers) -> torch.Tensor:
     """w [E, L], layers: L same-shape tensors -> [E, *shape] fp32 (grad flows to w only)."""
-    return _MixFn.apply(w, *[t.detach().contiguous() for t in layers])
+    return _MixFn.apply(w, *[t.detach() for t in layers])
 
 
 # --------------------------------------------------------------------------- #
@@ -272,4 +272,4 @@ class _ProcrustesFn(torch.autograd.Function):
 
 def procrustes(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor) -> torch.Tensor:
     """Per-sample attention-weighted Procrustes value [B]; differentiable in s, t, imp."""
-    return _ProcrustesFn.apply(s.contiguous(), t.contiguous().float(), imp.contiguous().float())
+    return _ProcrustesFn.apply(s, t.contiguous().float(), imp.contiguous().float())

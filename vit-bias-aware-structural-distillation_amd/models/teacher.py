@@ -172,7 +172,8 @@ def extract_intermediates(teacher: TeacherModel, x: torch.Tensor):
 
         def make_token_hook(i):
             def hook(mod, inp, out):
-                tokens[i] = _to_token_format(out, teacher.feature_format, teacher.has_cls_token).contiguous()
+                # a view of the block output (CLS stripped by offset): the kernels take batch-strided views
+                tokens[i] = _to_token_format(out, teacher.feature_format, teacher.has_cls_token)
             return hook
         hooks.append(module.register_forward_hook(make_token_hook(idx)))
         if teacher.attn_subpath is not None:

@@ -42,6 +42,16 @@ class DropPath(nn.Module):
         return x * mask / keep
 
 
+class MixedLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm; placeholder for the fused bf16-in / fp32-parameter kernel (next round).
+
+    torch's ROCm layer_norm refuses bf16 activations with fp32 parameters, so under autocast the
+    student pays one upcast and one downcast copy per call (torch's autocast policy).  Rounding
+    gamma/beta to bf16 instead would change the numerics relative to the reference, so the
+    stock behaviour is kept.
+    """
+
+
 class LayerScale(nn.Module):
     def __init__(self, dim: int, init_values: float):
         super().__init__()
@@ -96,11 +106,11 @@ class Mlp(nn.Module):
 class Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4.0, drop_path=0.0, init_values=None, eps=1e-6):
         super().__init__()
-        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.norm1 = MixedLayerNorm(dim, eps=eps)
         self.attn = Attention(dim, num_heads)
         self.ls1 = LayerScale(dim, init_values) if init_values else nn.Identity()
         self.drop_path1 = DropPath(drop_path)
-        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.norm2 = MixedLayerNorm(dim, eps=eps)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self.ls2 = LayerScale(dim, init_values) if init_values else nn.Identity()
         self.drop_path2 = DropPath(drop_path)
@@ -140,7 +150,7 @@ class VisionTransformer(nn.Module):
         dpr = [drop_path_rate * i / max(depth - 1, 1) for i in range(depth)]
         self.blocks = nn.ModuleList([
             Block(embed_dim, num_heads, mlp_ratio, dpr[i], init_values) for i in range(depth)])
-        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.norm = MixedLayerNorm(embed_dim, eps=1e-6)
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         self.grad_checkpointing = False
         if self.cls_token is not None:
