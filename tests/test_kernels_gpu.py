@@ -293,3 +293,27 @@ def test_batch_strided_views_are_consumed_without_copy(nat, dtype):
     imp = (torch.rand(B, T - 1, generator=g) + 0.1).cuda()
     for a, b in zip(nat.procrustes_prep(views[1], t, imp), nat.procrustes_prep(dense[1], t, imp)):
         torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_jacobi_two_matrices_per_workgroup_path(nat):
+    """batch >= 512 takes the NMAT = 2 kernel (odd batch: the last workgroup carries one matrix)."""
+    g = torch.Generator().manual_seed(21)
+    batch, m, n = 513, 40, 33
+    a = torch.randn(batch, m, n, generator=g) * torch.logspace(0, -3, n).view(1, 1, n)
+    ld = nat.jacobi_ld(m)
+    w = _colmajor(a.cuda(), ld)
+    sigma, sweeps = nat.jacobi_svd(w, m)
+    ref = torch.linalg.svdvals(a.double())
+    assert float((sigma.cpu().double() / ref - 1).abs().max()) < 5e-6
+    wf = w.cpu().double()[:, :, :m].transpose(1, 2)
+    aat = a.double() @ a.double().transpose(1, 2)
+    assert torch.allclose(wf @ wf.transpose(1, 2), aat, rtol=0, atol=3e-6 * float(aat.abs().max()))
+    assert int(sweeps.max()) < 40 and int(sweeps.min()) >= 1
+    # rank-masked blocks of different sizes sharing a workgroup
+    ks = torch.randint(2, n + 1, (batch,), generator=g)
+    b = torch.zeros(batch, n, n)
+    for i in range(batch):
+        b[i, :ks[i], :ks[i]] = torch.randn(int(ks[i]), int(ks[i]), generator=g)
+    w2 = _colmajor(b.cuda(), nat.jacobi_ld(n))
+    s2, _ = nat.jacobi_svd(w2, n, active=ks.int().cuda(), active_rows=True)
+    assert torch.allclose(s2.cpu().double(), torch.linalg.svdvals(b.double()), rtol=3e-5, atol=2e-6)

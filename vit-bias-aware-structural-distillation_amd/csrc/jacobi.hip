@@ -154,141 +154,179 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
 // (2k+1, 2k+2), every rotation is followed by a (logical) swap, and n consecutive steps visit
 // every column pair exactly once.  An 8-lane slot keeps its two columns X, Y in VGPRs for the
 // whole solve; the rotation itself touches no LDS.  Between steps each slot hands ONE column to a
-// neighbour through a double-buffered LDS mailbox (even->odd: Y goes to slot k-1, odd->even: X
-// goes to slot k+1), so per step one column per slot is written to and read from LDS instead of
-// two (the LDS-resident kernel above is bound by ds_write bandwidth), and one barrier per step
-// suffices.
+// neighbour through an LDS mailbox (even->odd: Y goes to slot k-1, odd->even: X goes to slot k+1).
+//
+// The kernel is bound by the per-step dependent chain (LDS hand-over -> dot -> 8-lane reduction
+// -> rotation parameters -> update -> hand-over), not by bandwidth, so NMAT = 2 lets every
+// workgroup carry two INDEPENDENT matrices through the same steps: their instruction streams
+// interleave in each wave (ILP) and they share the barriers.  NMAT = 1 double-buffers the mailbox
+// (one barrier per step); NMAT = 2 uses one mailbox per matrix and two barriers per step.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int MAXCH>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void jacobi_oe_kernel(
-    float* __restrict__ wg, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
+template <int MAXCH, int NMAT>
+__global__ __launch_bounds__(NMAT == 2 ? 768 : 1024)
+__attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void jacobi_oe_kernel(
+    float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
     float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, const int32_t* __restrict__ active,
     int active_rows) {
   extern __shared__ __align__(16) float lds[];
-  const int tid = threadIdx.x;
-  const int k = tid >> 3, sub = tid & 7;
-  const int S_all = (n + 1) >> 1;                 // slots that own real columns
+  constexpr int NBUF = (NMAT == 1) ? 2 : 1;
   constexpr int LDM = 32 * MAXCH;                  // mailbox column stride (all MAXCH chunks, no row guards)
-  float* mbox = lds;                               // [2][S_all][LDM]
-  float* s_sig = mbox + (size_t)2 * S_all * LDM;   // [n + 1]
-  int* s_rank = reinterpret_cast<int*>(s_sig + 260);   // [n + 1]
-  int* s_id = s_rank + 260;                        // [2][S_all] column ids travelling with the mailbox
-  int* s_flag = s_id + 2 * 132;                    // [2]
-  float* src = wg + (size_t)blockIdx.x * n * ld;
+  const int tid = threadIdx.x;
+  const int k = tid >> 3, sub = tid & 7, roff = sub * 4;
+  const int S_all = (n + 1) >> 1;                 // slots that own real columns
+  float* mbox = lds;                               // [NMAT][NBUF][S_all][LDM]
+  float* s_sig = mbox + (size_t)NMAT * NBUF * S_all * LDM;   // [n + 1]
+  int* s_rank = reinterpret_cast<int*>(s_sig + 260);          // [n + 1]
+  int* s_id = s_rank + 260;                        // [NMAT][NBUF][132] column ids travelling with the mailbox
+  float* s_nrm = reinterpret_cast<float*>(s_id + 2 * 2 * 132);   // [NMAT][NBUF][132] squared norms travelling along
+  int* s_flag = reinterpret_cast<int*>(s_nrm + 2 * 2 * 132);     // [2]
 
-  int n_act = n;
-  if (active) { n_act = active[blockIdx.x]; n_act = n_act < 2 ? 2 : (n_act > n ? n : n_act); }
-  int mrows = (m + 3) & ~3;
-  if (active && active_rows) { const int ma = (n_act + 3) & ~3; mrows = ma < mrows ? ma : mrows; }
-  const int n_e = n_act + (n_act & 1);             // line length (a zero phantom column pads odd n)
-  const int S = n_e >> 1;                          // active slots
-  const bool live = k < S;
-
-  v4f X[MAXCH], Y[MAXCH];
-  int idX = 2 * k, idY = 2 * k + 1;
+  float* src[NMAT];
+  int n_act[NMAT], mrows[NMAT], n_e[NMAT], S[NMAT], idX[NMAT], idY[NMAT];
+  bool live[NMAT];
+  v4f X[NMAT][MAXCH], Y[NMAT][MAXCH];
+  float nX[NMAT], nY[NMAT];                        // squared column norms, updated by a' = a - t g, b' = b + t g
+  int n_loop = 2;
 #pragma unroll
-  for (int ch = 0; ch < MAXCH; ++ch) {
-    const int r = sub * 4 + 32 * ch;
-    const bool in = live && r < mrows;
-    X[ch] = (in && idX < n_act) ? *reinterpret_cast<const v4f*>(src + (size_t)idX * ld + r) : (v4f){0.f, 0.f, 0.f, 0.f};
-    Y[ch] = (in && idY < n_act) ? *reinterpret_cast<const v4f*>(src + (size_t)idY * ld + r) : (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int mi = 0; mi < NMAT; ++mi) {
+    const int mat = blockIdx.x * NMAT + mi;
+    const bool exists = mat < batch;
+    src[mi] = wg + (size_t)(exists ? mat : 0) * n * ld;
+    int na = n;
+    if (active && exists) { na = active[mat]; na = na < 2 ? 2 : (na > n ? n : na); }
+    n_act[mi] = na;
+    int mr = (m + 3) & ~3;
+    if (active && active_rows) { const int ma = (na + 3) & ~3; mr = ma < mr ? ma : mr; }
+    mrows[mi] = mr;
+    n_e[mi] = na + (na & 1);                       // line length (a zero phantom column pads odd n)
+    S[mi] = n_e[mi] >> 1;
+    live[mi] = exists && (k < S[mi]);
+    if (exists && n_e[mi] > n_loop) n_loop = n_e[mi];
+    idX[mi] = 2 * k; idY[mi] = 2 * k + 1;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      const int r = roff + 32 * ch;
+      const bool in = live[mi] && r < mr;
+      X[mi][ch] = (in && idX[mi] < na) ? *reinterpret_cast<const v4f*>(src[mi] + (size_t)idX[mi] * ld + r) : (v4f){0.f, 0.f, 0.f, 0.f};
+      Y[mi][ch] = (in && idY[mi] < na) ? *reinterpret_cast<const v4f*>(src[mi] + (size_t)idY[mi] * ld + r) : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
   }
   if (tid < 2) s_flag[tid] = 0;
   __syncthreads();
 
   int used_sweeps = 0;
-  int step = 0;                                    // global step counter: even = (2k,2k+1) view
+  int step = 0;                                    // global step counter: even = (2k, 2k+1) view
 #pragma unroll 1
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     bool rotated = false;
-#pragma unroll 1
-    for (int t = 0; t < n_e; ++t, ++step) {
-      const bool even_view = (step & 1) == 0;
-      // in the odd view the last slot owns a single column (X) and slot 0's old first column idles
-      const bool pair_ok = live && (even_view || k < S - 1);
-      if (pair_ok) {
-        float alpha = 0.f, beta = 0.f, gamma = 0.f;
+    // exact squared norms once per sweep; inside the sweep they follow the rotation identities
+    // (drift ~ n eps only perturbs the rotation angle and the skip test, never the columns)
 #pragma unroll
-        for (int ch = 0; ch < MAXCH; ++ch) {
-          {
-            alpha = fmaf(X[ch].x, X[ch].x, fmaf(X[ch].y, X[ch].y, fmaf(X[ch].z, X[ch].z, fmaf(X[ch].w, X[ch].w, alpha))));
-            beta = fmaf(Y[ch].x, Y[ch].x, fmaf(Y[ch].y, Y[ch].y, fmaf(Y[ch].z, Y[ch].z, fmaf(Y[ch].w, Y[ch].w, beta))));
-            gamma = fmaf(X[ch].x, Y[ch].x, fmaf(X[ch].y, Y[ch].y, fmaf(X[ch].z, Y[ch].z, fmaf(X[ch].w, Y[ch].w, gamma))));
-          }
-        }
-        alpha = group8_sum(alpha);
-        beta = group8_sum(beta);
-        gamma = group8_sum(gamma);
-        if (gamma * gamma > tol * tol * alpha * beta && gamma != 0.f) {
-          rotated = true;
-          const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
-          const float tt = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.f)));
-          const float w1 = fmaf(tt, tt, 1.f);
-          float c = __builtin_amdgcn_rsqf(w1);
-          c = c * fmaf(-0.5f * w1, c * c, 1.5f);
-          const float s = c * tt;
-          const float tau = s * __builtin_amdgcn_rcpf(1.0f + c);
+    for (int mi = 0; mi < NMAT; ++mi) {
+      float ax = 0.f, ay = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) {
+        const v4f x = X[mi][ch], y = Y[mi][ch];
+        ax = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, ax))));
+        ay = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, fmaf(y.w, y.w, ay))));
+      }
+      nX[mi] = group8_sum(ax);
+      nY[mi] = group8_sum(ay);
+    }
+#pragma unroll 1
+    for (int t = 0; t < n_loop; ++t, ++step) {
+      const bool even_view = (step & 1) == 0;
+      const int buf = (NBUF == 2) ? (step & 1) : 0;
+#pragma unroll
+      for (int mi = 0; mi < NMAT; ++mi) {
+        // in the odd view the last slot owns a single column (X) and slot 0's old first column idles
+        const bool pair_ok = live[mi] && (even_view || k < S[mi] - 1);
+        if (pair_ok) {
+          const float alpha = nX[mi], beta = nY[mi];
+          float gamma = 0.f;
 #pragma unroll
           for (int ch = 0; ch < MAXCH; ++ch) {
-            {
+            const v4f x = X[mi][ch], y = Y[mi][ch];
+            gamma = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, gamma))));
+          }
+          gamma = group8_sum(gamma);
+          if (gamma * gamma > tol * tol * alpha * beta && gamma != 0.f) {
+            rotated = true;
+            const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
+            const float tt = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.f)));
+            const float w1 = fmaf(tt, tt, 1.f);
+            float c = __builtin_amdgcn_rsqf(w1);
+            c = c * fmaf(-0.5f * w1, c * c, 1.5f);
+            const float s = c * tt;
+            const float tau = s * __builtin_amdgcn_rcpf(1.0f + c);
+            nX[mi] = fmaf(-tt, gamma, alpha);
+            nY[mi] = fmaf(tt, gamma, beta);
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) {
+              const v4f x = X[mi][ch], y = Y[mi][ch];
               v4f nx, ny;
-              nx.x = fmaf(-s, fmaf(tau, X[ch].x, Y[ch].x), X[ch].x); ny.x = fmaf(s, fmaf(-tau, Y[ch].x, X[ch].x), Y[ch].x);
-              nx.y = fmaf(-s, fmaf(tau, X[ch].y, Y[ch].y), X[ch].y); ny.y = fmaf(s, fmaf(-tau, Y[ch].y, X[ch].y), Y[ch].y);
-              nx.z = fmaf(-s, fmaf(tau, X[ch].z, Y[ch].z), X[ch].z); ny.z = fmaf(s, fmaf(-tau, Y[ch].z, X[ch].z), Y[ch].z);
-              nx.w = fmaf(-s, fmaf(tau, X[ch].w, Y[ch].w), X[ch].w); ny.w = fmaf(s, fmaf(-tau, Y[ch].w, X[ch].w), Y[ch].w);
-              X[ch] = nx; Y[ch] = ny;
+              nx.x = fmaf(-s, fmaf(tau, x.x, y.x), x.x); ny.x = fmaf(s, fmaf(-tau, y.x, x.x), y.x);
+              nx.y = fmaf(-s, fmaf(tau, x.y, y.y), x.y); ny.y = fmaf(s, fmaf(-tau, y.y, x.y), y.y);
+              nx.z = fmaf(-s, fmaf(tau, x.z, y.z), x.z); ny.z = fmaf(s, fmaf(-tau, y.z, x.z), y.z);
+              nx.w = fmaf(-s, fmaf(tau, x.w, y.w), x.w); ny.w = fmaf(s, fmaf(-tau, y.w, x.w), y.w);
+              X[mi][ch] = nx; Y[mi][ch] = ny;
             }
           }
         }
       }
       // ---- hand one column over.  After the (logical) swap the pair is stored as (lo = Y, hi = X).
-      float* box = mbox + (size_t)(step & 1) * S_all * LDM;
-      int* idbox = s_id + (step & 1) * 132;
-      const int roff = sub * 4;
-      if (even_view) {
-        // even -> odd view: position 2k (held in Y) goes to slot k-1; slot 0's copy simply stays
-        // parked in box[0] of this buffer until the next odd -> even hand-over.  The new Y is slot
-        // k+1's old position 2k+2.
-        if (live) {
+      // even -> odd view: position 2k (held in Y) goes to slot k-1; slot 0's copy stays parked in
+      //   box[0] until the next odd -> even hand-over; the new Y is slot k+1's old position 2k+2.
+      // odd -> even view: position 2k+2 (held in X after the swap; the lone last slot did not swap)
+      //   goes to slot k+1; the new X is slot k-1's old position 2k (slot 0: the parked column).
 #pragma unroll
-          for (int ch = 0; ch < MAXCH; ++ch)
-            *reinterpret_cast<v4f*>(box + (size_t)k * LDM + roff + 32 * ch) = Y[ch];
-          if (sub == 0) idbox[k] = idY;
-        }
-        __syncthreads();
-        if (live && k < S - 1) {
+      for (int mi = 0; mi < NMAT; ++mi) {
+        float* box = mbox + ((size_t)mi * NBUF + buf) * S_all * LDM;
+        int* idbox = s_id + (mi * 2 + buf) * 132;
+        float* nbox = s_nrm + (mi * 2 + buf) * 132;
+        if (even_view) {
+          if (live[mi]) {
 #pragma unroll
-          for (int ch = 0; ch < MAXCH; ++ch)
-            Y[ch] = *reinterpret_cast<const v4f*>(box + (size_t)(k + 1) * LDM + roff + 32 * ch);
-          idY = idbox[k + 1];
-        }
-      } else {
-        // odd -> even view: position 2k+2 (held in X after the swap; the lone last slot did not
-        // swap) goes to slot k+1; the new X is slot k-1's old position 2k, and for slot 0 the column
-        // parked in the OTHER buffer one step ago.
-        if (live && k < S - 1) {
-#pragma unroll
-          for (int ch = 0; ch < MAXCH; ++ch)
-            *reinterpret_cast<v4f*>(box + (size_t)(k + 1) * LDM + roff + 32 * ch) = X[ch];
-          if (sub == 0) idbox[k + 1] = idX;
-        }
-        __syncthreads();
-        if (live) {
-          const float* rbox = (k == 0) ? mbox + (size_t)((step & 1) ^ 1) * S_all * LDM : box + (size_t)k * LDM;
-          const int* ridbox = (k == 0) ? s_id + ((step & 1) ^ 1) * 132 : idbox + k;
-          const bool lone = (k == S - 1);     // its single column stayed at position 2k+1 -> becomes Y
-#pragma unroll
-          for (int ch = 0; ch < MAXCH; ++ch) {
-            {
-              if (lone) Y[ch] = X[ch];
-              X[ch] = *reinterpret_cast<const v4f*>(rbox + roff + 32 * ch);
-            }
+            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(box + (size_t)k * LDM + roff + 32 * ch) = Y[mi][ch];
+            if (sub == 0) { idbox[k] = idY[mi]; nbox[k] = nY[mi]; }
           }
-          if (lone) idY = idX;
-          idX = ridbox[0];
+        } else if (live[mi] && k < S[mi] - 1) {
+#pragma unroll
+          for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(box + (size_t)(k + 1) * LDM + roff + 32 * ch) = X[mi][ch];
+          if (sub == 0) { idbox[k + 1] = idX[mi]; nbox[k + 1] = nX[mi]; }
         }
       }
+      __syncthreads();
+#pragma unroll
+      for (int mi = 0; mi < NMAT; ++mi) {
+        const float* box = mbox + ((size_t)mi * NBUF + buf) * S_all * LDM;
+        const int* idbox = s_id + (mi * 2 + buf) * 132;
+        const float* nbox = s_nrm + (mi * 2 + buf) * 132;
+        if (even_view) {
+          if (live[mi] && k < S[mi] - 1) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) Y[mi][ch] = *reinterpret_cast<const v4f*>(box + (size_t)(k + 1) * LDM + roff + 32 * ch);
+            idY[mi] = idbox[k + 1];
+            nY[mi] = nbox[k + 1];
+          }
+        } else if (live[mi]) {
+          const int pbuf = (NBUF == 2) ? (buf ^ 1) : 0;             // where slot 0 parked its column
+          const float* rbox = (k == 0) ? mbox + ((size_t)mi * NBUF + pbuf) * S_all * LDM : box + (size_t)k * LDM;
+          const int* ridbox = (k == 0) ? s_id + (mi * 2 + pbuf) * 132 : idbox + k;
+          const float* rnbox = (k == 0) ? s_nrm + (mi * 2 + pbuf) * 132 : nbox + k;
+          const bool lone = (k == S[mi] - 1);    // its single column stayed at position 2k+1 -> becomes Y
+#pragma unroll
+          for (int ch = 0; ch < MAXCH; ++ch) {
+            if (lone) Y[mi][ch] = X[mi][ch];
+            X[mi][ch] = *reinterpret_cast<const v4f*>(rbox + roff + 32 * ch);
+          }
+          if (lone) { idY[mi] = idX[mi]; nY[mi] = nX[mi]; }
+          idX[mi] = ridbox[0];
+          nX[mi] = rnbox[0];
+        }
+      }
+      if (NBUF == 1) __syncthreads();            // single mailbox: reads done before the next writes
     }
     used_sweeps = sweep + 1;
     if (rotated) s_flag[sweep & 1] = 1;
@@ -298,74 +336,77 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     __syncthreads();
     if (!any) break;
   }
-  // the solve always ends in the even view (n_e is even): slot k holds positions 2k (X) and 2k+1 (Y)
+  // n_loop is even, so the solve ends in the even view: slot k holds positions 2k (X) and 2k+1 (Y)
 
-  // ---- norms over the first norm_rows rows; the phantom column (id == n_act, only when n_act is odd)
-  //      gets -1 so that it ranks last and is dropped
-  for (int c = tid; c <= n; c += blockDim.x) s_sig[c] = 0.f;
-  __syncthreads();
-  if (live) {
-    float ax = 0.f, ay = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
-      const int r = sub * 4 + 32 * ch;
-      {
-        const float mx = (r + 0 < norm_rows) ? 1.f : 0.f, my = (r + 1 < norm_rows) ? 1.f : 0.f;
-        const float mz = (r + 2 < norm_rows) ? 1.f : 0.f, mw = (r + 3 < norm_rows) ? 1.f : 0.f;
-        ax = fmaf(mx * X[ch].x, X[ch].x, fmaf(my * X[ch].y, X[ch].y, fmaf(mz * X[ch].z, X[ch].z, fmaf(mw * X[ch].w, X[ch].w, ax))));
-        ay = fmaf(mx * Y[ch].x, Y[ch].x, fmaf(my * Y[ch].y, Y[ch].y, fmaf(mz * Y[ch].z, Y[ch].z, fmaf(mw * Y[ch].w, Y[ch].w, ay))));
-      }
-    }
-    ax = group8_sum(ax);
-    ay = group8_sum(ay);
-    if (sub == 0) {
-      s_sig[2 * k] = (idX >= n_act) ? -1.f : sqrtf(ax);
-      s_sig[2 * k + 1] = (idY >= n_act) ? -1.f : sqrtf(ay);
-    }
-  }
-  __syncthreads();
-  // positions 0 .. n_e-1 hold the active columns (one may be the phantom), n_e .. n-1 are the untouched
-  // zero columns of an `active` call; rank all of them (descending, ties by position)
-  const int n_tot = (n_e > n) ? n_e : n;
-  if (tid < n_tot) {
-    int rank = tid;
-    if (sort) {
-      const float mine = s_sig[tid];
-      rank = 0;
-      for (int c = 0; c < n_tot; ++c) {
-        const float o = s_sig[c];
-        rank += (o > mine) || (o == mine && c < tid);
-      }
-    } else if (tid < n_e) {
-      rank = -2;      // unsorted output: column id decides (filled in below)
-    }
-    s_rank[tid] = rank;
-  }
-  __syncthreads();
-  {
-    // every slot (live or not) writes the two positions it stands for
-    const int p0 = 2 * k, p1 = 2 * k + 1;
-    int d0 = (p0 < n_tot) ? s_rank[p0] : n, d1 = (p1 < n_tot) ? s_rank[p1] : n;
-    if (!sort) { d0 = live ? idX : p0; d1 = live ? idY : p1; }
-    const float sg0 = (p0 < n_tot) ? s_sig[p0] : -1.f, sg1 = (p1 < n_tot) ? s_sig[p1] : -1.f;
-    if (k < ((n_tot + 1) >> 1)) {
+  for (int mi = 0; mi < NMAT; ++mi) {
+    const int mat = blockIdx.x * NMAT + mi;
+    if (mat >= batch) break;                     // uniform across the workgroup
+    // ---- norms over the first norm_rows rows; the phantom column (id == n_act, only when n_act is
+    //      odd) gets -1 so that it ranks last and is dropped
+    __syncthreads();
+    for (int c = tid; c <= n; c += blockDim.x) s_sig[c] = 0.f;
+    __syncthreads();
+    if (live[mi]) {
+      float ax = 0.f, ay = 0.f;
 #pragma unroll
       for (int ch = 0; ch < MAXCH; ++ch) {
-        const int r = sub * 4 + 32 * ch;
-        if (r < ld) {
-          const v4f z4 = (v4f){0.f, 0.f, 0.f, 0.f};
-          const bool inr = r < mrows;
-          if (d0 >= 0 && d0 < n && p0 < n_tot) *reinterpret_cast<v4f*>(src + (size_t)d0 * ld + r) = (live && inr) ? X[ch] : z4;
-          if (d1 >= 0 && d1 < n && p1 < n_tot) *reinterpret_cast<v4f*>(src + (size_t)d1 * ld + r) = (live && inr) ? Y[ch] : z4;
-        }
+        const int r = roff + 32 * ch;
+        const float mx = (r + 0 < norm_rows) ? 1.f : 0.f, my = (r + 1 < norm_rows) ? 1.f : 0.f;
+        const float mz = (r + 2 < norm_rows) ? 1.f : 0.f, mw = (r + 3 < norm_rows) ? 1.f : 0.f;
+        const v4f x = X[mi][ch], y = Y[mi][ch];
+        ax = fmaf(mx * x.x, x.x, fmaf(my * x.y, x.y, fmaf(mz * x.z, x.z, fmaf(mw * x.w, x.w, ax))));
+        ay = fmaf(mx * y.x, y.x, fmaf(my * y.y, y.y, fmaf(mz * y.z, y.z, fmaf(mw * y.w, y.w, ay))));
       }
+      ax = group8_sum(ax);
+      ay = group8_sum(ay);
       if (sub == 0) {
-        if (d0 >= 0 && d0 < n && p0 < n_tot) sigma[(size_t)blockIdx.x * n + d0] = sg0 < 0.f ? 0.f : sg0;
-        if (d1 >= 0 && d1 < n && p1 < n_tot) sigma[(size_t)blockIdx.x * n + d1] = sg1 < 0.f ? 0.f : sg1;
+        s_sig[2 * k] = (idX[mi] >= n_act[mi]) ? -1.f : sqrtf(ax);
+        s_sig[2 * k + 1] = (idY[mi] >= n_act[mi]) ? -1.f : sqrtf(ay);
       }
     }
+    __syncthreads();
+    // positions 0 .. n_e-1 hold the active columns (one may be the phantom), n_e .. n-1 are the
+    // untouched zero columns of an `active` call; rank all of them (descending, ties by position)
+    const int n_tot = (n_e[mi] > n) ? n_e[mi] : n;
+    if (tid < n_tot) {
+      int rank = tid;
+      if (sort) {
+        const float mine = s_sig[tid];
+        rank = 0;
+        for (int c = 0; c < n_tot; ++c) {
+          const float o = s_sig[c];
+          rank += (o > mine) || (o == mine && c < tid);
+        }
+      }
+      s_rank[tid] = rank;
+    }
+    __syncthreads();
+    {
+      // every slot (live or not) writes the two positions it stands for
+      const int p0 = 2 * k, p1 = 2 * k + 1;
+      int d0 = (p0 < n_tot) ? s_rank[p0] : n, d1 = (p1 < n_tot) ? s_rank[p1] : n;
+      if (!sort) { d0 = live[mi] ? idX[mi] : p0; d1 = live[mi] ? idY[mi] : p1; }
+      const float sg0 = (p0 < n_tot) ? s_sig[p0] : -1.f, sg1 = (p1 < n_tot) ? s_sig[p1] : -1.f;
+      if (k < ((n_tot + 1) >> 1)) {
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+          const int r = roff + 32 * ch;
+          if (r < ld) {
+            const v4f z4 = (v4f){0.f, 0.f, 0.f, 0.f};
+            const bool inr = r < mrows[mi];
+            if (d0 >= 0 && d0 < n && p0 < n_tot) *reinterpret_cast<v4f*>(src[mi] + (size_t)d0 * ld + r) = (live[mi] && inr) ? X[mi][ch] : z4;
+            if (d1 >= 0 && d1 < n && p1 < n_tot) *reinterpret_cast<v4f*>(src[mi] + (size_t)d1 * ld + r) = (live[mi] && inr) ? Y[mi][ch] : z4;
+          }
+        }
+        if (sub == 0) {
+          if (d0 >= 0 && d0 < n && p0 < n_tot) sigma[(size_t)mat * n + d0] = sg0 < 0.f ? 0.f : sg0;
+          if (d1 >= 0 && d1 < n && p1 < n_tot) sigma[(size_t)mat * n + d1] = sg1 < 0.f ? 0.f : sg1;
+        }
+      }
+    }
+    if (sweeps_out && tid == 0) sweeps_out[mat] = used_sweeps;
   }
-  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = used_sweeps;
 }
 
 }  // namespace basd
@@ -385,22 +426,33 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   hipStream_t st = (hipStream_t)stream;
   // register-resident odd-even kernel: LDS only holds the double-buffered mailbox
   const int oe_ch = chunks <= 2 ? 2 : (chunks <= 4 ? 4 : (chunks <= 6 ? 6 : 7));
-  const size_t lds_oe = (size_t)2 * npairs * 32 * oe_ch * 4 + (260 + 260 + 264 + 8) * 4;
-  if (lds_oe <= BASD_JACOBI_LDS_BYTES && chunks <= 7 && npairs <= 128) {
-#define BASD_LAUNCH_OE(MC)                                                                           \
+  const size_t oe_scratch = (260 + 260 + 2 * 2 * 132 * 2 + 8) * 4;
+  // two matrices per workgroup (shared steps, ILP) once every CU would get at least two anyway
+  const size_t lds_oe2 = (size_t)2 * npairs * 32 * oe_ch * 4 + oe_scratch;       // NMAT 2, single mailbox each
+  const size_t lds_oe1 = lds_oe2;                                                // NMAT 1, double buffered
+  const bool fits = lds_oe1 <= BASD_JACOBI_LDS_BYTES && chunks <= 7 && npairs <= 128;
+#define BASD_LAUNCH_OE(MC, NM, GRID, LDSB)                                                            \
   do {                                                                                               \
-    hipFuncSetAttribute((const void*)jacobi_oe_kernel<MC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        (int)lds_oe);                                                                \
-    hipLaunchKernelGGL(jacobi_oe_kernel<MC>, dim3(batch), dim3(threads), lds_oe, st, w, m_rows, n_cols, \
-                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows);    \
+    hipFuncSetAttribute((const void*)jacobi_oe_kernel<MC, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        (int)(LDSB));                                                                \
+    hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
+                       n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows); \
   } while (0)
-    if (chunks <= 2) BASD_LAUNCH_OE(2);
-    else if (chunks <= 4) BASD_LAUNCH_OE(4);
-    else if (chunks <= 6) BASD_LAUNCH_OE(6);
-    else BASD_LAUNCH_OE(7);
-#undef BASD_LAUNCH_OE
+  if (fits && batch >= 512 && npairs <= 96 && oe_ch <= 6) {
+    const int grid2 = (batch + 1) / 2;
+    if (oe_ch == 2) BASD_LAUNCH_OE(2, 2, grid2, lds_oe2);
+    else if (oe_ch == 4) BASD_LAUNCH_OE(4, 2, grid2, lds_oe2);
+    else BASD_LAUNCH_OE(6, 2, grid2, lds_oe2);
+    return check_launch("jacobi_svd (odd-even x2)");
+  }
+  if (fits) {
+    if (oe_ch == 2) BASD_LAUNCH_OE(2, 1, batch, lds_oe1);
+    else if (oe_ch == 4) BASD_LAUNCH_OE(4, 1, batch, lds_oe1);
+    else if (oe_ch == 6) BASD_LAUNCH_OE(6, 1, batch, lds_oe1);
+    else BASD_LAUNCH_OE(7, 1, batch, lds_oe1);
     return check_launch("jacobi_svd (odd-even)");
   }
+#undef BASD_LAUNCH_OE
   const size_t lds_bytes = (size_t)n_cols * ld * 4 + (256 + 256 + 8) * 4;
   if (lds_bytes > BASD_JACOBI_LDS_BYTES)
     return fail(BASD_ERR_SHAPE, "jacobi_svd: %d x %d (ld %d) needs %zu B of LDS > 160 KiB", m_rows, n_cols, ld, lds_bytes);

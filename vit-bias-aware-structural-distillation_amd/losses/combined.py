@@ -54,13 +54,13 @@ class BASDLoss(nn.Module):
                            for j in teacher_indices])
         mixed_imp = torch.einsum("el,lbn->ebn", weights, imp)
 
-        geo_losses = []
-        for i, layer_idx in enumerate(self.token_layers):
+        students = []
+        for layer_idx in self.token_layers:
             s = student_intermediates[layer_idx]
             if s.shape[1] != self.num_student_tokens:
                 raise ValueError(f"student layer {layer_idx} has {s.shape[1]} tokens, expected {self.num_student_tokens}")
-            geo_losses.append(BF.procrustes(s, mixed[i], mixed_imp[i]).mean())
-        geo_each = torch.stack(geo_losses)
+            students.append(s)
+        geo_each = BF.procrustes_all(students, mixed, mixed_imp).mean(dim=1)      # [E]
         geo_loss = geo_each.mean()
 
         # UW-SO (reference combined.py:78-85): w_i = (1/L_i) / sum_j (1/L_j), detached

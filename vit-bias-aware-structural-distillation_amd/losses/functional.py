@@ -236,40 +236,57 @@ def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
 
 
 class _ProcrustesFn(torch.autograd.Function):
+    """All extraction points at once: inputs are E student tensors [B,N_s,D_s], the mixed teacher
+    tokens [E,B,N_t,D_t] and the mixed importance [E,B,N_t]; the E*B cross-covariances go through
+    ONE chain of batched launches (fp64 GEMMs, pivoted Cholesky, Jacobi, triangular inverse)."""
+
     @staticmethod
-    def forward(ctx, s, t, imp):
+    def forward(ctx, t_all, imp_all, *students):
         ops = get_ops()
-        n_s, n_t = s.shape[1], t.shape[1]
-        s_w, t_w, a, tr = ops.procrustes_prep(s, t, imp)
+        E = len(students)
+        n_s, n_t = students[0].shape[1], t_all.shape[2]
+        sws, tws, a_s, trs = [], [], [], []
+        for i in range(E):
+            s_w, t_w, a, tr = ops.procrustes_prep(students[i], t_all[i], imp_all[i])
+            sws.append(s_w); tws.append(t_w); a_s.append(a); trs.append(tr)
+        s_w, t_w, a, tr = torch.cat(sws), torch.cat(tws), torch.cat(a_s), torch.cat(trs)     # [E*B, ...]
         nuc, g = _polar_of_cross(s_w, t_w)
-        ctx.save_for_backward(s_w, t_w, a, g, imp)
-        ctx.n_t = n_t
-        ctx.s_dtype = s.dtype
-        return tr[:, 0] + tr[:, 1] - 2.0 * nuc
+        ctx.save_for_backward(s_w, t_w, a, g, imp_all)
+        ctx.n_t, ctx.E = n_t, E
+        ctx.s_dtype = students[0].dtype
+        return (tr[:, 0] + tr[:, 1] - 2.0 * nuc).view(E, -1)
 
     @staticmethod
     def backward(ctx, g_loss):
-        s_w, t_w, a, g, imp = ctx.saved_tensors
+        s_w, t_w, a, g, imp_all = ctx.saved_tensors
+        E = ctx.E
         n_s, n_t = s_w.shape[1], ctx.n_t
-        gl = g_loss.float().view(-1, 1, 1)
+        gl = g_loss.float().reshape(-1, 1, 1)
         g_sw = 2.0 * gl * (s_w - t_w @ g.transpose(1, 2))
         g_tw = 2.0 * gl * (t_w - s_w @ g)
         root = a.sqrt().unsqueeze(-1)
         g_s = (root * g_sw).to(ctx.s_dtype)
         g_t = root * g_tw
         g_a = ((g_sw * s_w).sum(-1) + (g_tw * t_w).sum(-1)) / (2.0 * a)
+        imp = imp_all.float().reshape(-1, n_t)
         if n_t != n_s:
             r = resample_matrix(n_t, n_s, s_w.device)                  # [n_s, n_t]
-            tot = (imp.float() @ r.t()).sum(-1, keepdim=True)
+            tot = (imp @ r.t()).sum(-1, keepdim=True)
             g_raw = (g_a - (a * g_a).sum(-1, keepdim=True)) / tot
             g_imp = g_raw @ r
             g_t = torch.matmul(r.t(), g_t)
         else:
-            tot = imp.float().sum(-1, keepdim=True)
+            tot = imp.sum(-1, keepdim=True)
             g_imp = (g_a - (a * g_a).sum(-1, keepdim=True)) / tot
-        return g_s, g_t, g_imp
+        b = g_s.shape[0] // E
+        return (g_t.view(E, b, n_t, -1), g_imp.view(E, b, n_t), *g_s.view(E, b, n_s, -1).unbind(0))
+
+
+def procrustes_all(students, t_all: torch.Tensor, imp_all: torch.Tensor) -> torch.Tensor:
+    """students: E tensors [B,N_s,D_s]; t_all [E,B,N_t,D_t]; imp_all [E,B,N_t] -> values [E, B]."""
+    return _ProcrustesFn.apply(t_all.contiguous().float(), imp_all.contiguous().float(), *students)
 
 
 def procrustes(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor) -> torch.Tensor:
     """Per-sample attention-weighted Procrustes value [B]; differentiable in s, t, imp."""
-    return _ProcrustesFn.apply(s, t.contiguous().float(), imp.contiguous().float())
+    return procrustes_all([s], t.unsqueeze(0), imp.unsqueeze(0))[0]
