@@ -89,10 +89,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path for the product kernels)")
-    torch.cuda.set_device(local_rank)
+    # BASD_DIST_BACKEND=gloo + several ranks on one GPU is a rehearsal mode for boxes with a single
+    # device (the driver's multi-GPU runs use nccl = RCCL, one rank per GPU)
+    backend = os.environ.get("BASD_DIST_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", local_dev)
 
     import basd_amd._native as native
     from basd_amd.config import load_config
