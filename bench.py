@@ -60,7 +60,8 @@ class KernelTimer:
                 e.record()
                 self.records[_name].append((s, e))
                 if _name == "jacobi_svd":
-                    self.meta[_name].append((a[0].shape[0], a[0].shape[1], a[1]))
+                    # (batch, n_cols, m_rows, rank-masked?) -- masked launches sweep a smaller block
+                    self.meta[_name].append((a[0].shape[0], a[0].shape[1], a[1], k.get("active") is not None, s, e))
                 return out
             setattr(self.native, name, wrapped)
 
@@ -80,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--grad-checkpointing", action="store_true")
     args = ap.parse_args()
 
@@ -155,21 +156,28 @@ def main():
         # columns), sweeps_nominal = 8.
         roof = None
         if "jacobi_svd" in ks:
-            flops = 0.0
-            for (b, n, m) in timer.meta["jacobi_svd"]:
+            flops, tot_ms, launches = 0.0, 0.0, 0
+            for (b, n, m, masked, ev_s, ev_e) in timer.meta["jacobi_svd"]:
+                if masked:
+                    continue          # rank-masked principal-angle launches: block size is data dependent
                 flops += b * 8 * (n * (n - 1) / 2) * 14.0 * m
-            tot_s = ks["jacobi_svd"]["total_ms"] / 1e3
-            achieved = flops / tot_s / 1e12
-            roof = {"kernel": "basd::jacobi_kernel (LDS one-sided Jacobi, all launches of a step)",
+                tot_ms += ev_s.elapsed_time(ev_e)
+                launches += 1
+            achieved = flops / (tot_ms / 1e3) / 1e12
+            roof = {"kernel": "basd::jacobi_oe_kernel (register-resident one-sided Jacobi; the full-size launches of a "
+                              "step: selector eigenproblems + the E*B Procrustes cores)",
                     "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                     "frac": achieved / 157.3, "traffic": None,
-                    "avg_launch_ms": ks["jacobi_svd"]["avg_ms"],
-                    "ms_per_step": ks["jacobi_svd"]["total_ms"] / args.steps}
+                    "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / args.steps,
+                    "ms_per_step": tot_ms / args.steps,
+                    "note": "LDS/VALU-bound kernel priced against the fp32 vector = matrix peak; algorithmic flops = "
+                            "8 sweeps x n(n-1)/2 pairs x 14 m per matrix (DESIGN.md section 5)"}
         vit_flops = global_batch * ((4 if args.grad_checkpointing else 3) * F_STUDENT + F_TEACHER)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_step import cpu_step_images_per_sec
-            cpu = cpu_step_images_per_sec(batch=args.cpu_batch)
+            print("[bench] GPU timing done; timing the CPU baseline sample", file=sys.stderr, flush=True)
+            cpu = cpu_step_images_per_sec(batch=args.cpu_batch, timed_steps=3, warmup=1)
         line = {
             "metric": "images/sec BASD train step, DeiT-T student / ViT-B teacher bs=256",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

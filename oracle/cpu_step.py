@@ -23,7 +23,13 @@ def cpu_step_images_per_sec(*, student="deit_tiny_patch16_224", teacher="vit_bas
     from oracle import basd_oracle as O
     from oracle.synth import token_layers
 
-    threads = os.cpu_count() or 1
+    # the GPU box gives one-GPU jobs a 16-core share; os.cpu_count() reports the whole host and
+    # oversubscribing OpenMP threads slows the SVD-heavy oracle by more than 10x
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("BASD_CPU_THREADS", "16"))))
     torch.set_num_threads(threads)
     torch.manual_seed(seed)
     t_model = create_vit(teacher, num_classes=0, img_size=img).eval()
@@ -81,11 +87,16 @@ def cpu_step_images_per_sec(*, student="deit_tiny_patch16_224", teacher="vit_bas
                 p.grad = None
         return float(out["loss"])
 
+    import sys
     for k in range(warmup):
+        t_w = time.perf_counter()
         step(k)
+        print(f"[cpu_baseline] warm-up step {k}: {time.perf_counter() - t_w:.1f} s ({threads} threads)", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for k in range(timed_steps):
+        t_s = time.perf_counter()
         step(warmup + k)
+        print(f"[cpu_baseline] timed step {k}: {time.perf_counter() - t_s:.1f} s", file=sys.stderr, flush=True)
     dt = (time.perf_counter() - t0) / timed_steps
     return {
         "value": batch / dt, "unit": "images/sec", "cores": threads, "kind": "port",

@@ -236,29 +236,62 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
     const int64_t ba = ra / rows_per_batch, bb = rb / rows_per_batch;      // strided [B, N, D] views
     const unsigned short* xa = x + ba * batch_stride + (ra - ba * rows_per_batch) * d_in + 8 * (lane >> 4);
     const unsigned short* xb = x + bb * batch_stride + (rb - bb * rows_per_batch) * d_in + 8 * (lane >> 4);
-    for (int k0 = 0; k0 < d_in; k0 += KC2) {
-      __syncthreads();                       // previous chunk's fragment reads (or the Gram phase) are done
-      // stage the three P splits of this K chunk: 3 * D_OUT rows of 64 bytes
-      for (int e = tid; e < 3 * D_OUT * 4; e += 256) {
-        const int q = e & 3, rc = e >> 2;    // rc = split * D_OUT + col
-        const int s = rc / D_OUT, col = rc - s * D_OUT;
-        const uint4 v = *reinterpret_cast<const uint4*>(psplit + s * split_stride + (size_t)col * d_in + k0 + 8 * q);
-        *reinterpret_cast<uint4*>(Pl + (size_t)rc * PROW + 16 * q) = v;
+    // software pipeline over K chunks: the global loads of chunk c+1 (three P splits -> registers,
+    // A fragments) are issued before the MFMAs of chunk c and land in the OTHER LDS buffer after
+    // them; one barrier per chunk.  (The unpipelined loop spent ~5 us per chunk waiting on L2.)
+    constexpr int PVEC = (3 * D_OUT * 4 + 255) / 256;          // uint4 per thread per chunk
+    uint4 pre[PVEC];
+    bf16x8 a0n, a1n;
+    auto fetch = [&](int k0) {
+#pragma unroll
+      for (int v = 0; v < PVEC; ++v) {
+        const int e = tid + 256 * v;
+        const int q = e & 3, rc = e >> 2;
+        const int sp = rc / D_OUT, col = rc - sp * D_OUT;
+        pre[v] = (rc < 3 * D_OUT)
+                     ? *reinterpret_cast<const uint4*>(psplit + sp * split_stride + (size_t)col * d_in + k0 + 8 * q)
+                     : make_uint4(0, 0, 0, 0);
       }
-      bf16x8 a0 = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
-      if (ra < rows) a0 = *reinterpret_cast<const bf16x8*>(xa + k0);
-      if (rb < rows) a1 = *reinterpret_cast<const bf16x8*>(xb + k0);
-      __syncthreads();
+      a0n = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      a1n = a0n;
+      if (ra < rows) a0n = *reinterpret_cast<const bf16x8*>(xa + k0);
+      if (rb < rows) a1n = *reinterpret_cast<const bf16x8*>(xb + k0);
+    };
+    auto stash = [&](unsigned char* buf) {
+#pragma unroll
+      for (int v = 0; v < PVEC; ++v) {
+        const int e = tid + 256 * v;
+        const int q = e & 3, rc = e >> 2;
+        if (rc < 3 * D_OUT) *reinterpret_cast<uint4*>(buf + (size_t)rc * PROW + 16 * q) = pre[v];
+      }
+    };
+    constexpr size_t PBUF = (size_t)3 * D_OUT * PROW;
+    __syncthreads();                           // the Gram phase of the previous tile no longer reads Z
+    fetch(0);
+    stash(Pl);
+    bf16x8 a0 = a0n, a1 = a1n;
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < d_in; k0 += KC2) {
+      const bool more = k0 + KC2 < d_in;
+      if (more) fetch(k0 + KC2);
+      const unsigned char* Pc = Pl + cur * PBUF;
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
           const bf16x8 b = *reinterpret_cast<const bf16x8*>(
-              Pl + (size_t)(s * D_OUT + c * 16 + (lane & 15)) * PROW + 16 * (lane >> 4));
+              Pc + (size_t)(s * D_OUT + c * 16 + (lane & 15)) * PROW + 16 * (lane >> 4));
           zacc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, zacc[0][c], 0, 0, 0);
           zacc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, zacc[1][c], 0, 0, 0);
         }
       }
+      if (more) {
+        stash(Pl + (cur ^ 1) * PBUF);
+        a0 = a0n; a1 = a1n;
+      }
+      cur ^= 1;
+      __syncthreads();
     }
     __syncthreads();                          // all fragment reads done before Z overlays the P buffer
 #pragma unroll
@@ -309,7 +342,7 @@ template <int NCT>
 static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_batch, int64_t batch_stride,
                              const void* psplit, double* gram, double* colsum, hipStream_t st) {
   constexpr int D_OUT = NCT * 16;
-  const size_t p_bytes = (size_t)3 * D_OUT * PROW;
+  const size_t p_bytes = (size_t)2 * 3 * D_OUT * PROW;      // double-buffered P chunk
   const size_t z_bytes = (size_t)TM2 * (D_OUT + 16) * 4;
   const size_t lds = p_bytes > z_bytes ? p_bytes : z_bytes;
   const int64_t ntiles = (rows + TM2 - 1) / TM2;

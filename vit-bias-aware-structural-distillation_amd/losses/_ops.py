@@ -24,3 +24,8 @@ def set_ops(provider) -> None:
     """Tests only."""
     global _ops
     _ops = provider
+
+
+def is_emulated() -> bool:
+    """True only inside the CPU test-suite (a test provider was installed with set_ops)."""
+    return _ops is not None and getattr(_ops, "__name__", "").endswith("_emul")
