@@ -164,10 +164,20 @@ def main():
                 tot_ms += ev_s.elapsed_time(ev_e)
                 launches += 1
             achieved = flops / (tot_ms / 1e3) / 1e12
+            # HBM bytes per launch of the biggest Jacobi launch (E*B matrices) from the committed PMC passes
+            # (profiles/r01_pmc_hbm_traffic.json; bench.py cannot read PMC counters itself)
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                    for key, v in json.load(f)["kernels"].items():
+                        if key.startswith("jacobi_oe_kernel<6, 2>"):
+                            traffic = v["hbm_bytes_per_launch"]
+            except OSError:
+                pass
             roof = {"kernel": "basd::jacobi_oe_kernel (register-resident one-sided Jacobi; the full-size launches of a "
                               "step: selector eigenproblems + the E*B Procrustes cores)",
                     "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": achieved / 157.3, "traffic": None,
+                    "frac": achieved / 157.3, "traffic": traffic,
                     "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / args.steps,
                     "ms_per_step": tot_ms / args.steps,
                     "note": "LDS/VALU-bound kernel priced against the fp32 vector = matrix peak; algorithmic flops = "

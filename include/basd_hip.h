@@ -55,6 +55,8 @@ const char* basd_last_error(void);
 /* z = X P^T (fp32 MFMA), gram = z^T z and colsum = 1^T z accumulated in fp64.
  * x: [rows, d_in] row-major (dtype code), proj: [d_out, d_in] fp32 row-major,
  * gram: [d_out, d_out] fp64 (MUST be zeroed by the caller), colsum: [d_out] fp64 (zeroed).
+ * Only the LOWER 16x16 tiles of gram are accumulated (fp64 atomics are the kernel's HBM write
+ * traffic: 41 MB per call at d_out = 192); the caller mirrors them.
  * d_out <= 256 and d_out % 16 == 0; d_in % 32 == 0.
  * Strided token views: logical row r is token r % rows_per_batch of batch r / rows_per_batch and
  * lives at x + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * d_in (elements); a

@@ -128,6 +128,12 @@ def _token_view(x: torch.Tensor):
     return x, x.shape[0], x.shape[1], x.shape[0], 0
 
 
+def _mirror_lower(gram: torch.Tensor) -> torch.Tensor:
+    """The kernels accumulate the lower 16x16 tiles only (diagonal tiles are complete)."""
+    low = torch.tril(gram)
+    return low + torch.tril(gram, -1).t()
+
+
 def token_gram(x: torch.Tensor, proj: torch.Tensor):
     """x [M, d_in] or [B, N, d_in] view (f32/bf16), proj [d_out, d_in] f32 ->
     gram [d_out, d_out] f64, colsum [d_out] f64."""
@@ -142,10 +148,10 @@ def token_gram(x: torch.Tensor, proj: torch.Tensor):
         ps = split_bf16x3(proj)
         _check(lib().basd_token_gram_bf16x3(_ptr(x), i64(m), d_in, rpb, i64(bstride), _ptr(ps), d_out, _ptr(gram),
                                             _ptr(colsum), _stream()), "basd_token_gram_bf16x3")
-        return gram, colsum
+        return _mirror_lower(gram), colsum
     _check(lib().basd_token_gram(_ptr(x), _dtype_code(x), i64(m), d_in, rpb, i64(bstride), _ptr(proj), d_out,
                                  _ptr(gram), _ptr(colsum), _stream()), "basd_token_gram")
-    return gram, colsum
+    return _mirror_lower(gram), colsum
 
 
 def pchol(a: torch.Tensor, tol: float = 1e-13):

@@ -138,7 +138,6 @@ __global__ __launch_bounds__(512) void token_gram_kernel(const T* __restrict__ x
         const int j = jt * 16 + (lane & 15);
         const double v = gacc[gi][reg];
         atomicAdd(&gram[(size_t)i * d_out + j], v);
-        if (it != jt) atomicAdd(&gram[(size_t)j * d_out + i], v);
       }
     }
   }
@@ -331,7 +330,6 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
         const int j = jt * 16 + (lane & 15);
         const double v = gacc[gi][reg];
         atomicAdd(&gram[(size_t)i * D_OUT + j], v);
-        if (it != jt) atomicAdd(&gram[(size_t)j * D_OUT + i], v);
       }
     }
   }

@@ -83,37 +83,47 @@ def importance_from_attention(attn: torch.Tensor, has_cls_token: bool) -> torch.
 # --------------------------------------------------------------------------- #
 # selector weights
 # --------------------------------------------------------------------------- #
+@torch.no_grad()
+def teacher_frames(teacher_tokens, proj_t):
+    """Teacher half of the selector (no gradient): per-layer Gram statistics -> MP ranks (device
+    int32, no host sync) and rank-masked PCA frames.  Reference layer_selector.py:69-74, 133-138.
+
+    Returned dict can be handed to ``selector_weights(..., frames=...)``; the trainer computes it on
+    a side stream while the student forward runs (only 2 L small eigenproblems: 24 workgroups).
+    """
+    ops = get_ops()
+    L = len(teacher_tokens)
+    D = proj_t.shape[0]
+    m_t = teacher_tokens[0].shape[0] * teacher_tokens[0].shape[1]
+    unc, cen = [], []
+    for x in teacher_tokens:                            # layer_selector.py:71-73, :134-136
+        g, c = ops.token_gram(x, proj_t)                # [B, N, D] view, no copy
+        unc.append(g)
+        cen.append(g - torch.outer(c, c) / m_t)
+    sigma, u, _ = psd_eig(torch.stack(unc + cen))
+    ranks = ops.mp_rank(sigma[:L] ** 2, m_t, D, D - 1)  # int32 [L], stays on device
+    v_t, s_t = u[L:], sigma[L:]
+    idx = torch.arange(D, device=proj_t.device)
+    keep = (idx.unsqueeze(0) < ranks.unsqueeze(1)).float()      # [L, D]  (index < k_j)
+    return {"ranks": ranks, "keep": keep, "vm_t": v_t * keep.unsqueeze(-1), "sw": s_t * keep}
+
+
 class _SelectorWeightsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_temp, proj_s, proj_t, n_student, *tokens):
+    def forward(ctx, log_temp, proj_s, ranks, keep, vm_t, sw, *student):
         ops = get_ops()
-        student = tokens[:n_student]
-        teacher = tokens[n_student:]
-        E, L = len(student), len(teacher)
+        E, L = len(student), vm_t.shape[0]
         D = proj_s.shape[0]
         dev = proj_s.device
 
         mats = []
-        m_t = teacher[0].shape[0] * teacher[0].shape[1]
-        cen_t = []
-        for x in teacher:                               # layer_selector.py:71-73, :134-136
-            g, c = ops.token_gram(x, proj_t)             # [B, N, D] view, no copy
-            mats.append(g)
-            cen_t.append(g - torch.outer(c, c) / m_t)
-        mats.extend(cen_t)
         m_s = student[0].shape[0] * student[0].shape[1]
         for s in student:                               # layer_selector.py:84-92
             g, c = ops.token_gram(s, proj_s)
             mats.append(g - torch.outer(c, c) / m_s)
-        sigma, u, _ = psd_eig(torch.stack(mats))
-        ranks = ops.mp_rank(sigma[:L] ** 2, m_t, D, D - 1)          # int32 [L], stays on device
-        v_t, s_t = u[L:2 * L], sigma[L:2 * L]
-        v_s, lam_s = u[2 * L:], sigma[2 * L:].double() ** 2
+        sigma_s, v_s, _ = psd_eig(torch.stack(mats))
+        lam_s = sigma_s.double() ** 2
 
-        idx = torch.arange(D, device=dev)
-        keep = (idx.unsqueeze(0) < ranks.unsqueeze(1)).float()      # [L, D]  (index < k_j)
-        vm_t = v_t * keep.unsqueeze(-1)
-        sw = s_t * keep
         a_full = torch.einsum("ibd,jcd->ijbc", v_s, vm_t)           # [E, L, D(b), D(c)]
         a_bar = a_full * keep.view(1, L, D, 1)                      # rows b < k_j
 
@@ -143,11 +153,10 @@ class _SelectorWeightsFn(torch.autograd.Function):
 
         ctx.save_for_backward(log_temp, proj_s, wts, d2, tau, t_seed, v_s, lam_s, *student)
         ctx.n_student = E
-        ctx.mark_non_differentiable(ranks)
-        return wts, ranks, pre
+        return wts, pre
 
     @staticmethod
-    def backward(ctx, g_w, _g_ranks, g_pre_out):
+    def backward(ctx, g_w, g_pre_out):
         log_temp, proj_s, wts, d2, tau, t_seed, v_s, lam_s, *student = ctx.saved_tensors
         E = ctx.n_student
         g_pre = wts * (g_w - (wts * g_w).sum(dim=1, keepdim=True))
@@ -171,15 +180,19 @@ class _SelectorWeightsFn(torch.autograd.Function):
             # centring z = s P^T over rows == centring s (linear map), so d loss / d s = (s - mean) W
             centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
             grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
-        n_teacher = len(ctx.needs_input_grad) - 4 - E
-        return (g_lt, None, None, None, *grads, *([None] * n_teacher))
+        return (g_lt, None, None, None, None, None, *grads)
 
 
-def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_temperatures):
-    """-> (weights [E, L] with grad, ranks int32 [L] on device, pre_softmax [E, L])."""
-    student = list(student_tokens)          # batch-strided views (CLS-stripped block outputs) are consumed in place
-    teacher = [t.detach() for t in teacher_tokens]
-    return _SelectorWeightsFn.apply(log_temperatures, proj_s, proj_t, len(student), *student, *teacher)
+def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_temperatures, frames=None):
+    """-> (weights [E, L] with grad, ranks int32 [L] on device, pre_softmax [E, L]).
+
+    ``frames`` = a ``teacher_frames`` result computed earlier (e.g. on a side stream)."""
+    if frames is None:
+        frames = teacher_frames([t.detach() for t in teacher_tokens], proj_t)
+    # batch-strided views (CLS-stripped block outputs) are consumed in place
+    wts, pre = _SelectorWeightsFn.apply(log_temperatures, proj_s, frames["ranks"], frames["keep"], frames["vm_t"],
+                                        frames["sw"], *student_tokens)
+    return wts, frames["ranks"], pre
 
 
 # --------------------------------------------------------------------------- #

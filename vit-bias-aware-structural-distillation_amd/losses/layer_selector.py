@@ -58,6 +58,7 @@ class GrassmannianLayerSelector(nn.Module):
             torch.full((num_extraction_points,), math.log(math.exp(1.0) - 1)))
         self._ranks_dev: torch.Tensor | None = None
         self._rank_keys: list[int] = []
+        self._frames = None            # teacher half precomputed by precompute_teacher()
         self.last_weights: torch.Tensor | None = None
         self.last_pre_softmax: torch.Tensor | None = None
 
@@ -72,12 +73,24 @@ class GrassmannianLayerSelector(nn.Module):
             return {}
         return dict(zip(self._rank_keys, self._ranks_dev.tolist()))
 
+    def precompute_teacher(self, all_teacher_tokens) -> None:
+        """Optional: run the teacher half of the selector (Gram statistics, MP ranks, PCA frames) ahead
+        of ``forward`` -- e.g. on a side stream while the student forward runs.  Consumed by the next
+        ``mixing_weights`` / ``forward`` call."""
+        teacher_indices = sorted(all_teacher_tokens.keys())
+        self._frames = (teacher_indices,
+                        BF.teacher_frames([all_teacher_tokens[j].detach() for j in teacher_indices], self.proj_t))
+
     def mixing_weights(self, student_tokens_per_layer, all_teacher_tokens, extraction_indices):
         teacher_indices = sorted(all_teacher_tokens.keys())
+        frames = None
+        if self._frames is not None and self._frames[0] == teacher_indices:
+            frames = self._frames[1]
+        self._frames = None
         weights, ranks, pre = BF.selector_weights(
             [student_tokens_per_layer[l] for l in extraction_indices],
             [all_teacher_tokens[j] for j in teacher_indices],
-            self.proj_s, self.proj_t, self.log_temperatures)
+            self.proj_s, self.proj_t, self.log_temperatures, frames=frames)
         self._ranks_dev, self._rank_keys = ranks, teacher_indices
         self.last_weights, self.last_pre_softmax = weights.detach(), pre.detach()
         return weights, teacher_indices

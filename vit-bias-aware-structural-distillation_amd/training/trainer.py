@@ -72,6 +72,15 @@ class Trainer:
         self.num_classes = config.model.num_classes
         self.use_mixup = True
         self.autocast_dtype = torch.bfloat16
+        self.overlap_teacher_stats = True
+        self._side = None
+
+    def _side_stream(self):
+        if self.device.type != "cuda" or not self.overlap_teacher_stats:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # ------------------------------------------------------------------ step
     def train_step(self, batch: dict):
@@ -81,11 +90,25 @@ class Trainer:
             student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
         else:
             mixed_targets = targets
+        # frozen teacher first: its selector statistics (12 Gram passes + 24 small eigenproblems that
+        # occupy 24 of the 256 CUs) then run on a side stream underneath the student forward
+        t_tokens, t_importance = extract_intermediates(self._teacher, clean)
+        side = self._side_stream()
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.basd_loss.layer_selector.precompute_teacher(t_tokens)
         with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
             logits, s_tokens = _extract_student(
                 self.model, student_imgs, self.basd_loss.token_layers,
                 layer_paths=self._student_layer_paths, has_cls_token=self._student_has_cls)
-        t_tokens, t_importance = extract_intermediates(self._teacher, clean)
+        if side is not None:
+            main.wait_stream(side)
+            frames = self.basd_loss.layer_selector._frames
+            if frames is not None:
+                for t in frames[1].values():
+                    t.record_stream(main)
         loss = self.basd_loss(logits.float(), mixed_targets, s_tokens, t_tokens, t_importance)
         loss.backward()
         self.reducer.finish()
