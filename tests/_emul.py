@@ -166,6 +166,13 @@ def wgrad_supported(n, k):
     return n % 64 == 0 and k % 64 == 0 and n >= 64 and k >= 64
 
 
-def wgrad_bf16(dy, x, need_bias=True):
+def wgrad_bf16(dy, x, need_bias=True, out_w=None, out_b=None):
     dw = dy.float().t() @ x.float()
-    return dw, (dy.float().sum(0) if need_bias else None)
+    db = dy.float().sum(0) if (need_bias or out_b is not None) else None
+    if out_w is not None:
+        out_w.add_(dw)
+        dw = out_w
+    if out_b is not None:
+        out_b.add_(db)
+        db = out_b
+    return dw, db

@@ -103,3 +103,30 @@ def test_checkpoint_roundtrip(tmp_path):
     torch.testing.assert_close(trainer.flat.data, snap)
     sd = torch.load(tmp_path / cfg.run.name / "checkpoints" / "final_model.pth", weights_only=True)
     assert "blocks.0.attn.qkv.weight" in sd["model_state_dict"] and "cls_token" in sd["model_state_dict"]
+
+
+def test_linear_direct_gradient_sink_equals_autograd_accumulation():
+    """BasdLinear accumulating into the flat gradient slots (no AccumulateGrad) == returning grads."""
+    from basd_amd.models.linear import BasdLinear
+    from basd_amd.training.optim import FlatParams
+    torch.manual_seed(0)
+    a, b = BasdLinear(64, 128), BasdLinear(64, 128)
+    b.load_state_dict(a.state_dict())
+    flat = FlatParams(list(b.parameters()))
+    flat.enable_bf16_shadow()
+    fired = []
+    for q in b.parameters():
+        q._basd_ready = (lambda q=q: fired.append(q.shape))
+    x = torch.randn(4, 70, 64)
+    for mod in (a, b):
+        for _ in range(2):                      # two backward passes: accumulation semantics
+            mod(x).square().sum().backward()
+    assert len(fired) == 4
+    torch.testing.assert_close(b.weight.grad, a.weight.grad, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(b.bias.grad, a.bias.grad, rtol=1e-5, atol=1e-4)
+    assert b.weight.grad.data_ptr() == flat.grad.data_ptr()
+    # the bf16 shadow follows the master weights after refresh
+    with torch.no_grad():
+        flat.data.mul_(2.0)
+    flat.refresh_bf16()
+    torch.testing.assert_close(b.weight._basd_bf16.float(), b.weight.detach(), rtol=1e-2, atol=1e-3)

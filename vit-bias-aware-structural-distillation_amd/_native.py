@@ -331,15 +331,20 @@ def wgrad_supported(n: int, k: int) -> bool:
     return n % 64 == 0 and k % 64 == 0 and n >= 64 and k >= 64
 
 
-def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True):
-    """dy [M, N], x [M, K] bf16 -> (dw [N, K] fp32, db [N] fp32 | None)."""
+def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True, out_w: torch.Tensor | None = None,
+               out_b: torch.Tensor | None = None):
+    """dy [M, N], x [M, K] bf16 -> (dw [N, K] fp32, db [N] fp32 | None).
+
+    With ``out_w`` / ``out_b`` (fp32, contiguous, e.g. views of the flat gradient buffer) the kernel
+    ACCUMULATES into them and they are returned as is."""
     _need_cuda(dy, x)
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
     dy, x = dy.contiguous(), x.contiguous()
     m, n = dy.shape
     k = x.shape[1]
-    dw = torch.zeros(n, k, dtype=torch.float32, device=dy.device)
-    db = torch.zeros(n, dtype=torch.float32, device=dy.device) if need_bias else None
+    dw = out_w if out_w is not None else torch.zeros(n, k, dtype=torch.float32, device=dy.device)
+    db = out_b if out_b is not None else (torch.zeros(n, dtype=torch.float32, device=dy.device) if need_bias else None)
+    assert dw.is_contiguous() and dw.dtype == torch.float32 and dw.shape == (n, k)
     _check(lib().basd_wgrad_bf16(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _stream()),
            "basd_wgrad_bf16")
     return dw, db

@@ -19,22 +19,43 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x16 = x.to(torch.bfloat16)
-        w16 = weight.to(torch.bfloat16)
+        # FlatParams.refresh_bf16() casts every parameter with ONE kernel per step; fall back to a
+        # per-call cast when the module is used outside the trainer
+        w16 = getattr(weight, "_basd_bf16", None)
+        if w16 is None:
+            w16 = weight.to(torch.bfloat16)
+        b16 = None
+        if bias is not None:
+            b16 = getattr(bias, "_basd_bf16", None)
+            if b16 is None:
+                b16 = bias.to(torch.bfloat16)
         ctx.save_for_backward(x16, w16)
-        ctx.has_bias = bias is not None
+        ctx.weight, ctx.bias = weight, bias
         ctx.x_dtype = x.dtype
-        return F.linear(x16, w16, None if bias is None else bias.to(torch.bfloat16))
+        return F.linear(x16, w16, b16)
 
     @staticmethod
     def backward(ctx, g):
         x16, w16 = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
         g16 = g.to(torch.bfloat16).contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = (g16 @ w16).to(ctx.x_dtype)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = get_ops().wgrad_bf16(g16.reshape(-1, g16.shape[-1]), x16.reshape(-1, x16.shape[-1]),
-                                          need_bias=ctx.has_bias)
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            sink_w = getattr(weight, "_basd_grad", None)
+            sink_b = getattr(bias, "_basd_grad", None) if bias is not None else None
+            dy2, x2 = g16.reshape(-1, g16.shape[-1]), x16.reshape(-1, x16.shape[-1])
+            if sink_w is not None and (bias is None or sink_b is not None):
+                # accumulate straight into the flat fp32 gradient buffer: no temporary, no
+                # AccumulateGrad add kernel; tell the data-parallel reducer the slots are ready
+                get_ops().wgrad_bf16(dy2, x2, need_bias=bias is not None, out_w=sink_w, out_b=sink_b)
+                for p in (weight, bias):
+                    ready = getattr(p, "_basd_ready", None) if p is not None else None
+                    if ready is not None:
+                        ready()
+            else:
+                gw, gb = get_ops().wgrad_bf16(dy2, x2, need_bias=bias is not None)
         return gx, gw, gb
 
 

@@ -57,7 +57,10 @@ class GradientReducer:
                 self._bucket_of[idx] = b
         self._pending = [len(m) for _, _, m in self.buckets]
         for idx, p in enumerate(flat.params):
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+            hook = self._make_hook(idx)
+            self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+            # kernels that accumulate straight into the flat buffer (no AccumulateGrad) call this instead
+            p._basd_ready = (lambda h=hook, q=p: h(q))
 
     def _make_hook(self, idx):
         def hook(_param):

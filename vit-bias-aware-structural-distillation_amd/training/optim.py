@@ -30,11 +30,29 @@ class FlatParams:
         self.offsets, self.numel = offs, total
         self.data = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.data16 = None
         for p, o in zip(self.params, offs):
             n = p.numel()
             self.data[o:o + n].copy_(p.data.reshape(-1).float())
             p.data = self.data[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
+
+    def enable_bf16_shadow(self, params=None) -> None:
+        """Keep a bf16 copy of the whole buffer (refreshed by ONE cast kernel per step) and expose, on
+        each listed parameter, ``_basd_bf16`` (its bf16 view) and ``_basd_grad`` (its fp32 gradient
+        slot) for kernels that read the half-precision weight / accumulate gradients directly."""
+        self.data16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.data.device)
+        chosen = None if params is None else {id(p) for p in params}
+        for p, o in zip(self.params, self.offsets):
+            if chosen is None or id(p) in chosen:
+                n = p.numel()
+                p._basd_bf16 = self.data16[o:o + n].view(p.shape)
+                p._basd_grad = self.grad[o:o + n].view(p.shape)
+        self.refresh_bf16()
+
+    def refresh_bf16(self) -> None:
+        if self.data16 is not None:
+            self.data16.copy_(self.data)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -64,6 +64,9 @@ class Trainer:
         self.flat = FlatParams(list(student_model.parameters()) + list(self.basd_loss.parameters()))
         self.optimizer = AdamWScheduleFree(self.flat, lr=config.training.learning_rate,
                                            weight_decay=config.training.weight_decay)
+        from ..models.linear import BasdLinear
+        lin_params = [q for m in student_model.modules() if isinstance(m, BasdLinear) for q in m.parameters()]
+        self.flat.enable_bf16_shadow(lin_params)
         self.reducer = GradientReducer(self.flat, bucket_bytes=bucket_bytes)
         self.reducer.broadcast_parameters()
         self.optimizer.z.copy_(self.flat.data)
@@ -86,6 +89,7 @@ class Trainer:
     def train_step(self, batch: dict):
         """One optimisation step on a device-resident batch {"clean","augmented","label"}."""
         clean, student_imgs, targets = batch["clean"], batch["augmented"], batch["label"]
+        self.flat.refresh_bf16()          # one cast kernel for every Linear weight of the student
         if self.use_mixup:
             student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
         else:
