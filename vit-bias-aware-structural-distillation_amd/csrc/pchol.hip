@@ -32,10 +32,9 @@ __global__ __launch_bounds__(768) void pchol_lds_kernel(const double* __restrict
   extern __shared__ __align__(16) double X[];                 // packed lower triangle
   const int tri_n = n * (n + 1) / 2;
   double* s_d = X + tri_n;                                     // [n] residual diagonal
-  double* s_redv = s_d + n;                                    // [16]
-  int* s_perm = reinterpret_cast<int*>(s_redv + 16);           // [n]
-  int* s_redi = s_perm + n;                                    // [16]
-  int* s_ctl = s_redi + 16;                                    // [2]: pivot position, stop flag
+  double* s_redv = s_d + n;                                    // [2][16] pivot candidates per wave (double buffered)
+  int* s_perm = reinterpret_cast<int*>(s_redv + 32);           // [n]
+  int* s_redi = s_perm + n;                                    // [2][16]
   const int tid = threadIdx.x, nt = blockDim.x;
   const double* A = a_all + (size_t)blockIdx.x * n * n;
   double* Lw = lw_all + (size_t)blockIdx.x * n * n;
@@ -48,36 +47,40 @@ __global__ __launch_bounds__(768) void pchol_lds_kernel(const double* __restrict
   }
   for (int i = tid; i < n; i += nt) { s_d[i] = A[(size_t)i * n + i]; s_perm[i] = i; }
   __syncthreads();
-  double dmax0 = 0.0;
   int rank = n;
   const int row_l = tid >> 2, part = tid & 3;
-  for (int k = 0; k < n; ++k) {
-    // ---- pivot: argmax of the residual diagonal over positions >= k
-    {
-      double v = -1.0e300; int idx = n;
-      for (int i = k + tid; i < n; i += nt) {
-        const double di = s_d[i];
-        if (di > v || (di == v && i < idx)) { v = di; idx = i; }
-      }
+  const int nw = nt >> 6;
+  // Two barriers per step: (A) after the pivot candidates of every wave are in LDS -- each thread
+  // then reduces the <= 12 candidates itself and performs its share of the symmetric swap --
+  // (B) after the swap.  Column k is then formed, the residual diagonal updated and the NEXT
+  // step's pivot candidates reduced per wave before barrier (A) of the next step.  The pivot
+  // factor's diagonal entry is sqrt(pivot residual), which every thread already holds.
+  auto wave_argmax_to_lds = [&](double v, int idx, int slot) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-      }
-      if ((tid & 63) == 0) { s_redv[tid >> 6] = v; s_redi[tid >> 6] = idx; }
-      __syncthreads();
-      if (tid == 0) {
-        double bv = s_redv[0]; int bi = s_redi[0];
-        for (int w = 1; w < (nt >> 6); ++w)
-          if (s_redv[w] > bv || (s_redv[w] == bv && s_redi[w] < bi)) { bv = s_redv[w]; bi = s_redi[w]; }
-        s_ctl[0] = bi;
-        s_redv[0] = bv;
-      }
-      __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
-    const int p = s_ctl[0];
-    const double pval = s_redv[0];
+    if ((tid & 63) == 0) { s_redv[slot * 16 + (tid >> 6)] = v; s_redi[slot * 16 + (tid >> 6)] = idx; }
+  };
+  {
+    double v = -1.0e300; int idx = n;
+    for (int i = tid; i < n; i += nt) {
+      const double di = s_d[i];
+      if (di > v || (di == v && i < idx)) { v = di; idx = i; }
+    }
+    wave_argmax_to_lds(v, idx, 0);
+  }
+  double dmax0 = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const int slot = k & 1;
+    __syncthreads();                                           // (A)
+    double pval = s_redv[slot * 16]; int p = s_redi[slot * 16];
+    for (int w = 1; w < nw; ++w) {
+      const double ov = s_redv[slot * 16 + w]; const int oi = s_redi[slot * 16 + w];
+      if (ov > pval || (ov == pval && oi < p)) { pval = ov; p = oi; }
+    }
     if (k == 0) dmax0 = pval;
     if (!(pval > tol * dmax0) || !(pval > 0.0)) { rank = k; break; }
     // ---- symmetric swap of positions k and p inside the packed triangle
@@ -96,9 +99,12 @@ __global__ __launch_bounds__(768) void pchol_lds_kernel(const double* __restrict
         }
       }
     }
-    __syncthreads();
-    // ---- column k: v_i = A[i,k] - sum_{j<k} L[i,j] L[k,j]   (i >= k), 4 lanes per row
-    double vloc = 0.0;
+    __syncthreads();                                           // (B)
+    // ---- column k: v_i = A[i,k] - sum_{j<k} L[i,j] L[k,j]   (i > k), 4 lanes per row.
+    //      l_kk = sqrt(residual diagonal of the pivot) is known to every thread (pval): nothing to
+    //      broadcast, and nobody reads X[k,k] while row k's group overwrites it.
+    const double lkk = sqrt(pval);
+    double dnew = -1.0e300;
     const int i = k + row_l;
     if (i < n) {
       const double* xi = X + tri(i, 0);
@@ -107,18 +113,17 @@ __global__ __launch_bounds__(768) void pchol_lds_kernel(const double* __restrict
       for (int j = part; j < k; j += 4) acc = fma(xi[j], xk[j], acc);
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
-      vloc = xi[k] - acc;
+      const double col = (i == k) ? lkk : (xi[k] - acc) / lkk;
+      if (i != k) dnew = s_d[i] - col * col;
+      if (part == 0) {
+        X[tri(i, k)] = col;
+        if (i != k) s_d[i] = dnew;
+      }
     }
-    if (i == k && part == 0) s_redv[1] = vloc;               // v_k
-    __syncthreads();
-    const double lkk = sqrt(fmax(s_redv[1], 0.0));
-    if (i < n && part == 0) {
-      const double col = (i == k) ? lkk : vloc / lkk;
-      X[tri(i, k)] = col;
-      s_d[i] -= col * col;
-    }
-    __syncthreads();
+    // next step's pivot candidates (positions > k): one value per row group, reduced per wave
+    wave_argmax_to_lds((part == 0 && i < n) ? dnew : -1.0e300, i, slot ^ 1);
   }
+  __syncthreads();
   // ---- scatter to the caller's layout (rows in ORIGINAL order, column-major by step)
   for (int e = tid; e < n * n; e += nt) {
     const int k = e / n, i = e - k * n;                       // step k, position i
@@ -269,7 +274,7 @@ extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, flo
   if (batch <= 0) return BASD_OK;
   if (n < 1 || n > 256 || ld < n || ld > 256 + 64)
     return fail(BASD_ERR_SHAPE, "pchol_f64: bad shape n=%d ld=%d", n, ld);
-  const size_t lds = ((size_t)n * (n + 1) / 2 + n + 16) * 8 + ((size_t)n + 16 + 2) * 4 + 64;
+  const size_t lds = ((size_t)n * (n + 1) / 2 + n + 32) * 8 + ((size_t)n + 32 + 2) * 4 + 64;
   if (lds <= 160 * 1024 && n <= 192) {
     hipFuncSetAttribute((const void*)pchol_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(pchol_lds_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, a, n, tol, w0, ld,
