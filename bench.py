@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,12 +120,29 @@ def main():
                                  "mix_grad_dots", "procrustes_prep", "wgrad_bf16", "sf_adamw_step", "mp_rank"])
     timer.install()
 
-    for i in range(args.warmup):
+    # a few eager steps first: rank sanity check + (events cannot be recorded inside a captured graph)
+    # the per-kernel device-event timings used for the roofline object
+    eager_probe = 3
+    timer.active = True
+    for i in range(eager_probe):
         loss, _ = trainer.train_step(batch)
         if i == 0:
+            timer.active = False
             ranks = trainer.basd_loss.layer_selector.subspace_ranks
             if min(ranks.values()) < 1 or not torch.isfinite(loss):
                 raise SystemExit(f"synthetic batch gives a rank-0 teacher layer / non-finite loss: {ranks} {loss}")
+            for n_ in timer.records:          # drop the first (cold) step from the statistics
+                timer.records[n_].clear()
+                timer.meta[n_].clear()
+            timer.active = True
+    torch.cuda.synchronize()
+    timer.active = False
+    probe_steps = eager_probe - 1
+    graphed = False
+    if not args.eager:
+        graphed = trainer.enable_graph(batch)
+    for i in range(args.warmup):
+        loss, _ = trainer.train_step(batch)
 
     def barrier():
         if world > 1:
@@ -132,7 +150,12 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
-    timer.active = True
+    timer.active = not graphed          # graph replays cannot carry events; eager runs time live
+    if not graphed:
+        for n_ in timer.records:
+            timer.records[n_].clear()
+            timer.meta[n_].clear()
+        probe_steps = args.steps
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps):
@@ -183,8 +206,12 @@ def main():
                               "cores of a step, 192x192 each)",
                     "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                     "frac": achieved / 157.3, "traffic": traffic,
-                    "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / args.steps,
-                    "ms_per_step": tot_ms / args.steps,
+                    "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / probe_steps,
+                    "ms_per_step": tot_ms / probe_steps,
+                    "measured_in": ("the timed region (eager)" if not graphed else
+                                    f"{probe_steps} instrumented eager steps of the same process before the timed region "
+                                    "(the timed steps replay one hipGraph; device events cannot be recorded inside it; "
+                                    "rocprofv3 of the same command sees the graph-launched kernels: profiles/)"),
                     "note": "LDS/VALU-bound kernel priced against the fp32 vector = matrix peak; algorithmic flops = "
                             "8 sweeps x n(n-1)/2 pairs x 14 m per matrix (DESIGN.md section 5)"}
         vit_flops = global_batch * ((4 if args.grad_checkpointing else 3) * F_STUDENT + F_TEACHER)
@@ -206,7 +233,8 @@ def main():
             "cpu_baseline": cpu,
             "vit_gemm": {"algorithmic_tflop_per_step": vit_flops / 1e12,
                          "tflops_if_whole_step": vit_flops / (ms_per_step / 1e3) / 1e12, "peak_bf16": 2500.0},
-            "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in ks.items()},
+            "kernel_ms_per_step": {k: v["total_ms"] / probe_steps for k, v in ks.items()},
+            "hip_graph": graphed, "hip_graph_error": trainer.graph_error,
             "host_enqueue_ms_per_step": 1e3 * host_s / args.steps,
             "loss": float(loss),
             "teacher_ranks": list(trainer.basd_loss.layer_selector.subspace_ranks.values()),

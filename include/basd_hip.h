@@ -117,7 +117,8 @@ int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int 
                  int32_t* ranks, void* stream);
 
 /* mixed[i] = sum_j w[i, j] * x_j   (all E mixes from ONE pass over the teacher layers)
- * x_layers: device array of L pointers to [elems] tensors (dtype code), w: [E, L] fp32,
+ * x_layers: HOST array of L device pointers to [elems] tensors (dtype code; the pointers are
+ * passed to the kernel by value, no device-side table), w: [E, L] fp32,
  * out: [E, elems] fp32 (contiguous).  Each source layer is a batch-strided view: logical element e
  * is at layer + (e / per_batch) * batch_stride + e % per_batch (contiguous: per_batch = elems). */
 int basd_mix_tokens(const void* const* x_layers, int x_dtype, int L, int E,

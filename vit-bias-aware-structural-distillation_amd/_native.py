@@ -208,8 +208,9 @@ def mp_rank(evals: torch.Tensor, rows: int, d: int, cap: int) -> torch.Tensor:
     return ranks
 
 
-def _ptr_table(layers: list[torch.Tensor]) -> torch.Tensor:
-    return torch.tensor([t.data_ptr() for t in layers], dtype=torch.int64, device=layers[0].device)
+def _ptr_table(layers: list[torch.Tensor]):
+    """Host array of device pointers (handed to the kernel by value: no H2D copy, graph-capturable)."""
+    return (ctypes.c_void_p * len(layers))(*[t.data_ptr() for t in layers])
 
 
 def _layer_views(layers):
@@ -237,7 +238,7 @@ def mix_tokens(layers: list[torch.Tensor], w: torch.Tensor) -> torch.Tensor:
     out = torch.empty((E,) + tuple(layers[0].shape), dtype=torch.float32, device=w.device)
     table = _ptr_table(layers)
     i64 = ctypes.c_int64
-    _check(lib().basd_mix_tokens(_ptr(table), code, L, E, _ptr(w.contiguous().float()), i64(elems), i64(per_batch),
+    _check(lib().basd_mix_tokens(table, code, L, E, _ptr(w.contiguous().float()), i64(elems), i64(per_batch),
                                  i64(bstride), _ptr(out), _stream()), "basd_mix_tokens")
     return out
 
@@ -253,7 +254,7 @@ def mix_grad_dots(layers: list[torch.Tensor], g: torch.Tensor) -> torch.Tensor:
     dots = torch.zeros(E, L, dtype=torch.float64, device=g.device)
     table = _ptr_table(layers)
     i64 = ctypes.c_int64
-    _check(lib().basd_mix_grad_dots(_ptr(table), code, L, E, _ptr(g.contiguous()), i64(elems), i64(per_batch),
+    _check(lib().basd_mix_grad_dots(table, code, L, E, _ptr(g.contiguous()), i64(elems), i64(per_batch),
                                     i64(bstride), _ptr(dots), _stream()), "basd_mix_grad_dots")
     return dots
 

@@ -11,6 +11,20 @@ namespace basd {
 char* err_buf();                       // thread-local, 256 bytes
 int fail(int code, const char* fmt, ...);
 
+// Raise a kernel's dynamic-LDS limit to the full 160 KiB ONCE per kernel (not per launch): the call is a
+// host-side attribute change and must not be issued while a stream is being captured into a hipGraph.
+inline void allow_full_lds(const void* fn) {
+  static thread_local const void* done[64];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == fn) return;
+  hipFuncAttributes attr;
+  int static_lds = 0;
+  if (hipFuncGetAttributes(&attr, fn) == hipSuccess) static_lds = (int)attr.sharedSizeBytes;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_lds);
+  if (ndone < 64) done[ndone++] = fn;
+}
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BASD_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));

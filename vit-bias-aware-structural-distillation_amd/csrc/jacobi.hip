@@ -433,8 +433,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   const bool fits = lds_oe1 <= BASD_JACOBI_LDS_BYTES && chunks <= 7 && npairs <= 128;
 #define BASD_LAUNCH_OE(MC, NM, GRID, LDSB)                                                            \
   do {                                                                                               \
-    hipFuncSetAttribute((const void*)jacobi_oe_kernel<MC, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        (int)(LDSB));                                                                \
+    allow_full_lds((const void*)jacobi_oe_kernel<MC, NM>);                                            \
     hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
                        n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows); \
   } while (0)
@@ -458,8 +457,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     return fail(BASD_ERR_SHAPE, "jacobi_svd: %d x %d (ld %d) needs %zu B of LDS > 160 KiB", m_rows, n_cols, ld, lds_bytes);
 #define BASD_LAUNCH_JACOBI(MC)                                                                     \
   do {                                                                                             \
-    hipFuncSetAttribute((const void*)jacobi_kernel<MC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        (int)lds_bytes);                                                           \
+    allow_full_lds((const void*)jacobi_kernel<MC>);                                                  \
     hipLaunchKernelGGL(jacobi_kernel<MC>, dim3(batch), dim3(threads), lds_bytes, st, w, m_rows,    \
                        n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active,       \
                        active_rows);                                                              \

@@ -276,7 +276,7 @@ extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, flo
     return fail(BASD_ERR_SHAPE, "pchol_f64: bad shape n=%d ld=%d", n, ld);
   const size_t lds = ((size_t)n * (n + 1) / 2 + n + 32) * 8 + ((size_t)n + 32 + 2) * 4 + 64;
   if (lds <= 160 * 1024 && n <= 192) {
-    hipFuncSetAttribute((const void*)pchol_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allow_full_lds((const void*)pchol_lds_kernel);
     hipLaunchKernelGGL(pchol_lds_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, a, n, tol, w0, ld,
                        lwork, piv, rank);
   } else {   // global-memory (L2-resident) fallback for 192 < n <= 256

@@ -13,6 +13,10 @@ namespace basd {
 constexpr int kMaxE = 8;
 constexpr int kMaxL = 64;
 
+// the L layer pointers travel in the kernel argument buffer (512 B): no device-side table, no
+// host-to-device copy per call (which would also break hipGraph capture)
+struct LayerPtrs { const void* p[kMaxL]; };
+
 template <typename T> struct Vec;
 template <> struct Vec<float> {
   static constexpr int N = 4;
@@ -35,7 +39,7 @@ template <> struct Vec<unsigned short> {   // bf16 bits
 };
 
 template <typename T, int E>
-__global__ __launch_bounds__(256) void mix_tokens_kernel(const T* const* __restrict__ layers, int L,
+__global__ __launch_bounds__(256) void mix_tokens_kernel(LayerPtrs layers, int L,
                                                          const float* __restrict__ w, int64_t nvec,
                                                          float* __restrict__ out, int64_t elems,
                                                          int64_t per_batch, int64_t batch_stride) {
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void mix_tokens_kernel(const T* const* __restr
   __shared__ float s_w[kMaxE * kMaxL];
   __shared__ const T* s_ptr[kMaxL];
   for (int i = threadIdx.x; i < E * L; i += blockDim.x) s_w[i] = w[i];
-  for (int i = threadIdx.x; i < L; i += blockDim.x) s_ptr[i] = layers[i];
+  for (int i = threadIdx.x; i < L; i += blockDim.x) s_ptr[i] = static_cast<const T*>(layers.p[i]);
   __syncthreads();
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
        v += (int64_t)gridDim.x * blockDim.x) {
@@ -76,14 +80,14 @@ __global__ __launch_bounds__(256) void mix_tokens_kernel(const T* const* __restr
 }
 
 template <typename T, int E>
-__global__ __launch_bounds__(256) void mix_grad_dots_kernel(const T* const* __restrict__ layers, int L,
+__global__ __launch_bounds__(256) void mix_grad_dots_kernel(LayerPtrs layers, int L,
                                                             const float* __restrict__ g, int64_t nvec,
                                                             int64_t elems, double* __restrict__ dots,
                                                             int64_t per_batch, int64_t batch_stride) {
   constexpr int N = Vec<T>::N;
   __shared__ const T* s_ptr[kMaxL];
   __shared__ double s_acc[kMaxE * kMaxL];
-  for (int i = threadIdx.x; i < L; i += blockDim.x) s_ptr[i] = layers[i];
+  for (int i = threadIdx.x; i < L; i += blockDim.x) s_ptr[i] = static_cast<const T*>(layers.p[i]);
   for (int i = threadIdx.x; i < E * L; i += blockDim.x) s_acc[i] = 0.0;
   __syncthreads();
   // per-thread fp32 partials over a bounded number of vectors, then fp64
@@ -260,14 +264,18 @@ namespace basd {
 template <typename T, int E>
 static void launch_mix(const void* const* layers, int L, const float* w, int64_t nvec, float* out,
                        int64_t elems, int64_t pb, int64_t bs, hipStream_t st) {
-  hipLaunchKernelGGL((mix_tokens_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st,
-                     (const T* const*)layers, L, w, nvec, out, elems, pb, bs);
+  LayerPtrs lp;
+  for (int i = 0; i < kMaxL; ++i) lp.p[i] = i < L ? layers[i] : nullptr;
+  hipLaunchKernelGGL((mix_tokens_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st, lp, L, w, nvec, out, elems,
+                     pb, bs);
 }
 template <typename T, int E>
 static void launch_dots(const void* const* layers, int L, const float* g, int64_t nvec, int64_t elems,
                         double* dots, int64_t pb, int64_t bs, hipStream_t st) {
-  hipLaunchKernelGGL((mix_grad_dots_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st,
-                     (const T* const*)layers, L, g, nvec, elems, dots, pb, bs);
+  LayerPtrs lp;
+  for (int i = 0; i < kMaxL; ++i) lp.p[i] = i < L ? layers[i] : nullptr;
+  hipLaunchKernelGGL((mix_grad_dots_kernel<T, E>), dim3(grid_for(nvec)), dim3(256), 0, st, lp, L, g, nvec, elems,
+                     dots, pb, bs);
 }
 
 template <typename T>

@@ -161,7 +161,7 @@ extern "C" int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_i
   hipStream_t st = (hipStream_t)stream;
 #define BASD_TG_LAUNCH(T, G)                                                                        \
   do {                                                                                              \
-    hipFuncSetAttribute((const void*)token_gram_kernel<T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    allow_full_lds((const void*)token_gram_kernel<T, G>);                                           \
     hipLaunchKernelGGL((token_gram_kernel<T, G>), dim3(grid), dim3(512), lds, st, (const T*)x, rows, d_in, \
                        rows_per_batch, batch_stride, proj, d_out, gram, colsum);                                                  \
   } while (0)
@@ -345,7 +345,7 @@ static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, int rows_per
   const size_t lds = p_bytes > z_bytes ? p_bytes : z_bytes;
   const int64_t ntiles = (rows + TM2 - 1) / TM2;
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
-  hipFuncSetAttribute((const void*)token_gram_bf16x3_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  allow_full_lds((const void*)token_gram_bf16x3_kernel<NCT>);
   hipLaunchKernelGGL((token_gram_bf16x3_kernel<NCT>), dim3(grid), dim3(256), lds, st, (const unsigned short*)x, rows,
                      d_in, rows_per_batch, batch_stride, (const unsigned short*)psplit, gram, colsum);
 }

@@ -81,7 +81,7 @@ extern "C" int basd_trinv_f64(const double* lwork, const int32_t* piv, const int
   if (n < 1 || lds > 160 * 1024)
     return fail(BASD_ERR_SHAPE, "trinv_f64: n=%d does not fit the LDS-resident packed triangle", n);
   // 4 lanes per row, rows strided by 192 per pass: two passes cover n <= 384 (v[2])
-  hipFuncSetAttribute((const void*)trinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  allow_full_lds((const void*)trinv_kernel);
   hipLaunchKernelGGL(trinv_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, lwork, piv, rank, n, out);
   return check_launch("trinv_f64");
 }

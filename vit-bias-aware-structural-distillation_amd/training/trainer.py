@@ -77,6 +77,8 @@ class Trainer:
         self.autocast_dtype = torch.bfloat16
         self.overlap_teacher_stats = True
         self._side = None
+        self._graph = None
+        self.graph_error = None
 
     def _side_stream(self):
         if self.device.type != "cuda" or not self.overlap_teacher_stats:
@@ -86,18 +88,14 @@ class Trainer:
         return self._side
 
     # ------------------------------------------------------------------ step
-    def train_step(self, batch: dict):
-        """One optimisation step on a device-resident batch {"clean","augmented","label"}."""
-        clean, student_imgs, targets = batch["clean"], batch["augmented"], batch["label"]
+    def _forward_backward(self, clean, student_imgs, mixed_targets):
+        """teacher fwd -> (side stream) teacher statistics || student fwd -> loss -> backward."""
         self.flat.refresh_bf16()          # one cast kernel for every Linear weight of the student
-        if self.use_mixup:
-            student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
-        else:
-            mixed_targets = targets
         # frozen teacher first: its selector statistics (12 Gram passes + 24 small eigenproblems that
         # occupy 24 of the 256 CUs) then run on a side stream underneath the student forward
         t_tokens, t_importance = extract_intermediates(self._teacher, clean)
         side = self._side_stream()
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
@@ -110,15 +108,75 @@ class Trainer:
         if side is not None:
             main.wait_stream(side)
             frames = self.basd_loss.layer_selector._frames
-            if frames is not None:
+            if frames is not None and not capturing:
                 for t in frames[1].values():
                     t.record_stream(main)
         loss = self.basd_loss(logits.float(), mixed_targets, s_tokens, t_tokens, t_importance)
         loss.backward()
-        self.reducer.finish()
+        return loss.detach(), logits.detach()
+
+    def enable_graph(self, batch: dict, warmup: int = 3) -> bool:
+        """Capture teacher fwd + student fwd + loss + backward into ONE hipGraph (static input
+        buffers).  A step then costs the host one graph launch instead of ~1 300 kernel launches:
+        on a shared host the eager step (26 ms of Python/launch work on an idle CPU) becomes
+        host-bound as soon as the CPU is contended.  MixUp/CutMix (host RNG), the gradient
+        all-reduce (one collective over the flat buffer) and the optimizer step (per-step scalars)
+        stay outside the graph.  Returns False (and stays eager) if capture is not possible."""
+        if self.device.type != "cuda":
+            return False
+        try:
+            b, c = batch["label"].shape[0], self.num_classes
+            self._g_clean = torch.empty_like(batch["clean"])
+            self._g_imgs = torch.empty_like(batch["augmented"])
+            self._g_targets = torch.empty(b, c, device=self.device)
+            self._g_clean.copy_(batch["clean"])
+            self._g_imgs.copy_(batch["augmented"])
+            self._g_targets.copy_(torch.nn.functional.one_hot(batch["label"], c).float())
+            self.reducer.paused = True
+            warm = torch.cuda.Stream(device=self.device)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for _ in range(warmup):
+                    self._forward_backward(self._g_clean, self._g_imgs, self._g_targets)
+                    self.flat.zero_grad()
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._g_loss, self._g_logits = self._forward_backward(self._g_clean, self._g_imgs, self._g_targets)
+            self.flat.zero_grad()
+            self._graph = graph
+            return True
+        except Exception as exc:      # capture is an optimisation: never lose the run over it
+            self._graph = None
+            self.reducer.paused = False
+            self.graph_error = f"{type(exc).__name__}: {exc}"
+            torch.cuda.synchronize()
+            self.flat.zero_grad()
+            return False
+
+    def train_step(self, batch: dict):
+        """One optimisation step on a device-resident batch {"clean","augmented","label"}."""
+        clean, student_imgs, targets = batch["clean"], batch["augmented"], batch["label"]
+        if self.use_mixup:
+            student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
+        else:
+            mixed_targets = targets
+        if self._graph is not None:
+            self._g_clean.copy_(clean)
+            self._g_imgs.copy_(student_imgs)
+            if mixed_targets.dim() == 1:
+                mixed_targets = torch.nn.functional.one_hot(mixed_targets, self.num_classes).float()
+            self._g_targets.copy_(mixed_targets)
+            self._graph.replay()
+            loss, logits = self._g_loss, self._g_logits
+            self.reducer.reduce_all()
+        else:
+            loss, logits = self._forward_backward(clean, student_imgs, mixed_targets)
+            self.reducer.finish()
         self.optimizer.step()
         self.optimizer.zero_grad()
-        return loss.detach(), logits.detach()
+        return loss, logits
 
     def _train_epoch(self, train_loader):
         total_loss = torch.tensor(0.0, device=self.device)
