@@ -161,6 +161,15 @@ int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int tr
 int basd_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, float* dw, float* db,
                     void* stream);
 
+/* LayerNorm of the ViT blocks (timm nn.LayerNorm, eps 1e-6): bf16 activations in/out, fp32 gamma/beta,
+ * fp32 statistics.  fwd saves mean / rstd [rows]; bwd writes dx and ACCUMULATES dgamma / dbeta
+ * (fp32 atomics; pass NULL for a frozen layer).  D % 8 == 0, D <= 2048. */
+int basd_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, int64_t rows, int D,
+                            float eps, void* y, float* mean, float* rstd, void* stream);
+int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, int64_t rows, int D, void* dx, float* dgamma, float* dbeta,
+                            void* stream);
+
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:
  *   v = b2 v + (1-b2) g^2 ; gn = g / (sqrt(v / bias_correction2) + eps) + wd * y

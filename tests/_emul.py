@@ -176,3 +176,28 @@ def wgrad_bf16(dy, x, need_bias=True, out_w=None, out_b=None):
         out_b.add_(db)
         db = out_b
     return dw, db
+
+
+def layernorm_supported(d):
+    return d % 8 == 0 and 8 <= d <= 2048
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    xf = x.float()
+    mean = xf.mean(-1)
+    var = ((xf - mean.unsqueeze(-1)) ** 2).mean(-1)
+    rstd = torch.rsqrt(var + eps)
+    y = ((xf - mean.unsqueeze(-1)) * rstd.unsqueeze(-1) * gamma + beta).to(torch.bfloat16)
+    return y, mean.reshape(-1), rstd.reshape(-1)
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+    d = x.shape[-1]
+    xf, dyf = x.float().reshape(-1, d), dy.float().reshape(-1, d)
+    xh = (xf - mean.unsqueeze(-1)) * rstd.unsqueeze(-1)
+    g = dyf * gamma
+    dx = rstd.unsqueeze(-1) * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    if dgamma is not None:
+        dgamma.add_((dyf * xh).sum(0))
+        dbeta.add_(dyf.sum(0))
+    return dx.to(torch.bfloat16).reshape(x.shape)

@@ -317,3 +317,29 @@ def test_jacobi_two_matrices_per_workgroup_path(nat):
     w2 = _colmajor(b.cuda(), nat.jacobi_ld(n))
     s2, _ = nat.jacobi_svd(w2, n, active=ks.int().cuda(), active_rows=True)
     assert torch.allclose(s2.cpu().double(), torch.linalg.svdvals(b.double()), rtol=3e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("rows,D", [(50432, 192), (1000, 768), (37, 64), (513, 1280)])
+def test_layernorm_fwd_bwd(nat, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2.0 + 0.5).bfloat16()
+    gamma = torch.randn(D, generator=g) * 0.5 + 1.0
+    beta = torch.randn(D, generator=g) * 0.1
+    dy = torch.randn(rows, D, generator=g).bfloat16()
+    y, mean, rstd = nat.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-6)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    yr.backward(dy.double())
+    assert torch.allclose(y.cpu().double(), yr.detach(), rtol=8e-3, atol=8e-3)          # bf16 output rounding
+    assert torch.allclose(mean.cpu().double(), x.double().mean(-1), rtol=0, atol=1e-5)
+    dgamma = torch.zeros(D, device="cuda")
+    dbeta = torch.zeros(D, device="cuda")
+    dx = nat.layernorm_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, rstd, dgamma, dbeta)
+    assert torch.allclose(dx.cpu().double(), xr.grad, rtol=1e-2, atol=1e-2 * float(xr.grad.abs().max()))
+    scale_g = float((dy.double().abs() * ((x.double() - x.double().mean(-1, keepdim=True)).abs())).sum(0).max()) + 1.0
+    assert torch.allclose(dgamma.cpu().double(), gr.grad, rtol=1e-4, atol=1e-5 * scale_g)
+    assert torch.allclose(dbeta.cpu().double(), br.grad, rtol=1e-4, atol=1e-5 * float(dy.double().abs().sum(0).max()))
+    # frozen layer: no parameter gradients requested
+    dx2 = nat.layernorm_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, rstd, None, None)
+    assert torch.equal(dx, dx2)

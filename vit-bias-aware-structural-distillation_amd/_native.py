@@ -21,7 +21,7 @@ JACOBI_LDS_BYTES = 163840
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
-    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16",
+    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
 )
 
 
@@ -349,3 +349,37 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True, out_w:
     _check(lib().basd_wgrad_bf16(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _stream()),
            "basd_wgrad_bf16")
     return dw, db
+
+
+def layernorm_supported(d: int) -> bool:
+    return d % 8 == 0 and 8 <= d <= 2048
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    """x [..., D] bf16 contiguous, gamma/beta fp32 -> (y bf16, mean [rows] fp32, rstd [rows] fp32)."""
+    _need_cuda(x, gamma, beta)
+    assert x.dtype == torch.bfloat16 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    x = x.contiguous()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(lib().basd_layernorm_fwd_bf16(_ptr(x), _ptr(gamma.contiguous()), _ptr(beta.contiguous()), ctypes.c_int64(rows),
+                                         d, ctypes.c_float(eps), _ptr(y), _ptr(mean), _ptr(rstd), _stream()),
+           "basd_layernorm_fwd_bf16")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                  dgamma: torch.Tensor | None, dbeta: torch.Tensor | None) -> torch.Tensor:
+    """-> dx bf16; dgamma / dbeta (fp32, may be None together) are accumulated into."""
+    _need_cuda(dy, x, gamma)
+    dy = dy.contiguous()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    _check(lib().basd_layernorm_bwd_bf16(_ptr(dy), _ptr(x), _ptr(gamma.contiguous()), _ptr(mean), _ptr(rstd),
+                                         ctypes.c_int64(rows), d, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()),
+           "basd_layernorm_bwd_bf16")
+    return dx

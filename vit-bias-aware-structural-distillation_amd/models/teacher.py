@@ -130,6 +130,9 @@ def load_teacher(model_name: str, img_size: int, *, weights: str | None = None, 
         p.requires_grad = False
     info = probe_model(model, img_size)
     model = model.to(dtype)
+    for m in model.modules():           # LayerNorm parameters stay fp32 (autocast semantics); the fused
+        if isinstance(m, nn.LayerNorm):   # kernel takes bf16 activations with fp32 gamma / beta
+            m.float()
     return TeacherModel(model=model, embed_dim=info["embed_dim"], heads_per_layer=info["heads_per_layer"],
                         depth=info["depth"], mlp_ratio=info["mlp_ratio"], layer_paths=info["layer_paths"],
                         attn_subpath=info["attn_subpath"], has_cls_token=info["has_cls_token"],

@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
+from ..losses._ops import get_ops, is_emulated
 from .linear import BasdLinear
 
 
@@ -42,14 +43,51 @@ class DropPath(nn.Module):
         return x * mask / keep
 
 
-class MixedLayerNorm(nn.LayerNorm):
-    """nn.LayerNorm; placeholder for the fused bf16-in / fp32-parameter kernel (next round).
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ops = get_ops()
+        y, mean, rstd = ops.layernorm_fwd(x, weight.detach().float(), bias.detach().float(), eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.weight, ctx.bias = weight, bias
+        return y
 
-    torch's ROCm layer_norm refuses bf16 activations with fp32 parameters, so under autocast the
-    student pays one upcast and one downcast copy per call (torch's autocast policy).  Rounding
-    gamma/beta to bf16 instead would change the numerics relative to the reference, so the
-    stock behaviour is kept.
-    """
+    @staticmethod
+    def backward(ctx, g):
+        ops = get_ops()
+        x, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        g = g.to(torch.bfloat16)
+        gw = gb = None
+        if weight.requires_grad:
+            sink_w, sink_b = getattr(weight, "_basd_grad", None), getattr(bias, "_basd_grad", None)
+            if sink_w is not None and sink_b is not None:      # straight into the flat gradient buffer
+                dx = ops.layernorm_bwd(g, x, weight.detach().float(), mean, rstd, sink_w, sink_b)
+                for p in (weight, bias):
+                    ready = getattr(p, "_basd_ready", None)
+                    if ready is not None:
+                        ready()
+            else:
+                gw = torch.zeros_like(weight, dtype=torch.float32)
+                gb = torch.zeros_like(bias, dtype=torch.float32)
+                dx = ops.layernorm_bwd(g, x, weight.detach().float(), mean, rstd, gw, gb)
+                gw, gb = gw.to(weight.dtype), gb.to(bias.dtype)
+        else:
+            dx = ops.layernorm_bwd(g, x, weight.detach().float(), mean, rstd, None, None)
+        return dx, gw, gb, None
+
+
+class MixedLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters) running on the fused HIP kernel for bf16 activations: bf16 in,
+    bf16 out, fp32 gamma / beta / statistics.  Equal to torch's autocast behaviour (fp32 layer_norm)
+    followed by the bf16 rounding the next Linear applies, without the up/down-cast copies and with a
+    one-kernel backward.  Other inputs (fp32 activations, CPU) take the stock path."""
+
+    def forward(self, x):
+        if (x.dtype == torch.bfloat16 and (x.is_cuda or is_emulated()) and self.elementwise_affine
+                and get_ops().layernorm_supported(x.shape[-1])):
+            return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
 
 
 class LayerScale(nn.Module):

@@ -65,7 +65,9 @@ class Trainer:
         self.optimizer = AdamWScheduleFree(self.flat, lr=config.training.learning_rate,
                                            weight_decay=config.training.weight_decay)
         from ..models.linear import BasdLinear
-        lin_params = [q for m in student_model.modules() if isinstance(m, BasdLinear) for q in m.parameters()]
+        from ..models.vit import MixedLayerNorm
+        lin_params = [q for m in student_model.modules() if isinstance(m, (BasdLinear, MixedLayerNorm))
+                      for q in m.parameters()]
         self.flat.enable_bf16_shadow(lin_params)
         self.reducer = GradientReducer(self.flat, bucket_bytes=bucket_bytes)
         self.reducer.broadcast_parameters()
