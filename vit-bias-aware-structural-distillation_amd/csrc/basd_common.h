@@ -31,6 +31,13 @@ inline int check_launch(const char* what) {
   return BASD_OK;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's
+// outstanding global stores (s_waitcnt vmcnt(0)), which puts an L2/HBM round trip into every step
+// of the latency-bound factorisation loops (28 us per step on an otherwise idle GPU).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
   return __uint_as_float(((unsigned int)b) << 16);
 }

@@ -12,6 +12,7 @@
 // A = W0 W0^T with W0[:,k] the k-th column; the Jacobi does not care about the
 // column order and a consumer that needs the triangular form gathers rows by
 // `piv`.
+#include <stdlib.h>
 #include "basd_common.h"
 
 namespace basd {
@@ -138,6 +139,185 @@ __global__ __launch_bounds__(768) void pchol_lds_kernel(const double* __restrict
   }
   for (int i = tid; i < n; i += nt) piv[i] = s_perm[i];
   if (tid == 0) rank_all[blockIdx.x] = rank;
+}
+
+// Register-resident version (default for n <= 192): right-looking, the whole residual matrix
+// lives in VGPRs -- 768 threads as 24 x 32 tiles of 8 rows x 6 columns (48 doubles per thread) --
+// and LDS only carries the scaled pivot row (1.5 KiB) from its owners to everybody.
+// Step k:  (A) everyone reads the pivot (p, residual d_p) that wave 0 selected; the 32 threads that
+// own row p publish  c_j = R[p][j] / sqrt(d_p)  (exact zeros at positions pivoted before, sqrt(d_p)
+// at p);  (B) every thread applies  R[i][j] -= c_i c_j  to its tile (7 LDS reads, 48 fp64 FMAs),
+// threads 64..255 store the column (c IS column k of the factor in ORIGINAL row order: no swaps,
+// no final scatter) and wave 0 updates the residual diagonal (same fma as the tile update, so it
+// stays bit-identical to R[i][i]) and picks the next pivot with DPP row reductions.
+// The left-looking LDS kernel above spends its step in a latency-bound dot product of length k
+// and a symmetric swap; this one has a fixed, short step (~0.5 us instead of 3.6 us).
+__device__ __forceinline__ void dpp_argmax_step(double& v, int& idx, int ctrl_sel) {
+  int lo = __double2loint(v), hi = __double2hiint(v), oi;
+  int olo, ohi;
+  switch (ctrl_sel) {   // dpp_ctrl must be an immediate
+    case 0: olo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); oi = __builtin_amdgcn_update_dpp(idx, idx, 0xB1, 0xF, 0xF, false); break;
+    case 1: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); oi = __builtin_amdgcn_update_dpp(idx, idx, 0x4E, 0xF, 0xF, false); break;
+    case 2: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); oi = __builtin_amdgcn_update_dpp(idx, idx, 0x141, 0xF, 0xF, false); break;
+    default: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); oi = __builtin_amdgcn_update_dpp(idx, idx, 0x140, 0xF, 0xF, false); break;
+  }
+  const double ov = __hiloint2double(ohi, olo);
+  if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
+
+// argmax over the 64 lanes of a wave (ties: lowest index); result uniform
+__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
+  dpp_argmax_step(v, idx, 0);      // quad_perm [1,0,3,2]
+  dpp_argmax_step(v, idx, 1);      // quad_perm [2,3,0,1]
+  dpp_argmax_step(v, idx, 2);      // row_half_mirror
+  dpp_argmax_step(v, idx, 3);      // row_mirror: every lane of a 16-lane row holds the row's winner
+  double bv = 0.0; int bi = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), r * 16);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), r * 16);
+    const int oi = __builtin_amdgcn_readlane(idx, r * 16);
+    const double ov = __hiloint2double(hi, lo);
+    if (r == 0 || ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  v = bv; idx = bi;
+}
+
+__global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict__ a_all, int n, double tol,
+                                                        float* __restrict__ w0_all, int ld,
+                                                        double* __restrict__ lw_all,
+                                                        int32_t* __restrict__ piv_all,
+                                                        int32_t* __restrict__ rank_all) {
+  __shared__ __align__(16) double s_c[192];
+  __shared__ double s_pv;
+  __shared__ int s_pi;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tr = tid >> 5, tc = tid & 31;          // tile row / tile column
+  const double* A = a_all + (size_t)blockIdx.x * n * n;
+  double* Lw = lw_all + (size_t)blockIdx.x * n * n;
+  float* W0 = w0_all + (size_t)blockIdx.x * n * ld;
+  int32_t* piv = piv_all + (size_t)blockIdx.x * n;
+
+  double R[8][6];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int i = 8 * tr + r;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int j = 6 * tc + c;
+      R[r][c] = (i < n && j < n) ? A[(size_t)i * n + j] : 0.0;
+    }
+  }
+  unsigned cdone = 0;                               // bit c: column 6 tc + c was pivoted (or is padding)
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+    if (6 * tc + c >= n) cdone |= 1u << c;
+  // wave 0: residual diagonal of rows lane, lane + 64, lane + 128
+  double d[3] = {0.0, 0.0, 0.0};
+  unsigned alive = 0;
+  if (tid < 64) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int t = lane + 64 * q;
+      if (t < n) { d[q] = A[(size_t)t * n + t]; alive |= 1u << q; }
+    }
+    double v = -1.0e300; int idx = n;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (((alive >> q) & 1) && d[q] > v) { v = d[q]; idx = lane + 64 * q; }
+    wave_argmax(v, idx);
+    if (tid == 0) { s_pv = v; s_pi = idx; }
+  }
+  int rank = n;
+  double dmax0 = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < n; ++k) {
+    lds_barrier();                                              // (A) pivot visible, s_c free
+    const double pval = s_pv;
+    const int p = s_pi;
+    if (k == 0) dmax0 = pval;
+    if (!(pval > tol * dmax0) || !(pval > 0.0)) { rank = k; break; }
+    if (tr == (p >> 3)) {                                       // owners of row p publish it
+      const int pr = p & 7;
+      double v[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[c] = R[0][c];
+#pragma unroll
+      for (int r = 1; r < 8; ++r)
+        if (pr == r) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v[c] = R[r][c];
+        }
+      const double lkk = sqrt(pval);
+      const double rinv = 1.0 / lkk;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double cj = ((cdone >> c) & 1) ? 0.0 : v[c] * rinv;
+        if (6 * tc + c == p) cj = lkk;
+        s_c[6 * tc + c] = cj;
+      }
+    }
+    {
+      const int q = p / 6;
+      if (tc == q) cdone |= 1u << (p - 6 * q);
+    }
+    lds_barrier();                                              // (B) column k visible
+    double cr[8], cc[6];
+    {
+      const double2* pr2 = reinterpret_cast<const double2*>(s_c + 8 * tr);
+      const double2* pc2 = reinterpret_cast<const double2*>(s_c + 6 * tc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const double2 t2 = pr2[r]; cr[2 * r] = t2.x; cr[2 * r + 1] = t2.y; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { const double2 t2 = pc2[c]; cc[2 * c] = t2.x; cc[2 * c + 1] = t2.y; }
+    }
+    if (tid < 64) {
+      double v = -1.0e300; int idx = n;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int t = lane + 64 * q;
+        const double c = s_c[t < 192 ? t : 0];
+        d[q] = fma(-c, c, d[q]);
+        if (t == p) alive &= ~(1u << q);
+        if (((alive >> q) & 1) && d[q] > v) { v = d[q]; idx = t; }
+      }
+      wave_argmax(v, idx);
+      if (tid == 0) { s_pv = v; s_pi = idx; piv[k] = p; }
+    } else if (tid < 256) {
+      const int t = tid - 64;
+      if (t < n) {
+        const double c = s_c[t];
+        Lw[(size_t)k * n + t] = c;
+        W0[(size_t)k * ld + t] = (float)c;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) R[r][c] = fma(-cr[r], cc[c], R[r][c]);
+  }
+  // ---- zero the steps beyond the numerical rank and the padding columns; complete the permutation
+  for (int e = tid; e < (n - rank) * n; e += blockDim.x) {
+    const int kk = rank + e / n, t = e - (e / n) * n;
+    Lw[(size_t)kk * n + t] = 0.0;
+    W0[(size_t)kk * ld + t] = 0.f;
+  }
+  if (ld > n)
+    for (int e = tid; e < n * (ld - n); e += blockDim.x) {
+      const int kk = e / (ld - n), t = n + (e - kk * (ld - n));
+      W0[(size_t)kk * ld + t] = 0.f;
+    }
+  if (tid < 64) {
+    int base = rank;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bool al = (alive >> q) & 1;
+      const unsigned long long m = __ballot(al);
+      if (al) piv[base + __popcll(m & ((1ull << lane) - 1ull))] = lane + 64 * q;
+      base += __popcll(m);
+    }
+    if (tid == 0) rank_all[blockIdx.x] = rank;
+  }
 }
 
 __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ a_all, int n,
@@ -275,7 +455,11 @@ extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, flo
   if (n < 1 || n > 256 || ld < n || ld > 256 + 64)
     return fail(BASD_ERR_SHAPE, "pchol_f64: bad shape n=%d ld=%d", n, ld);
   const size_t lds = ((size_t)n * (n + 1) / 2 + n + 32) * 8 + ((size_t)n + 32 + 2) * 4 + 64;
-  if (lds <= 160 * 1024 && n <= 192) {
+  static const bool use_lds_kernel = getenv("BASD_PCHOL_LDS") != nullptr;   // debugging aid: previous kernel
+  if (n <= 192 && !use_lds_kernel) {
+    hipLaunchKernelGGL(pchol_reg_kernel, dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, w0, ld,
+                       lwork, piv, rank);
+  } else if (lds <= 160 * 1024 && n <= 192) {
     allow_full_lds((const void*)pchol_lds_kernel);
     hipLaunchKernelGGL(pchol_lds_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, a, n, tol, w0, ld,
                        lwork, piv, rank);
