@@ -10,6 +10,7 @@
 // 2x2 MFMA tiles), K chunks of 16 staged through LDS in fp64, k-major so the
 // A/B fragments (one f64 per lane: A[i = lane&15][k = lane>>4]) are read from
 // consecutive addresses.
+#include <stdlib.h>
 #include "basd_common.h"
 
 namespace basd {
@@ -102,6 +103,131 @@ __global__ __launch_bounds__(256) void bgemm_f64_kernel(const TA* __restrict__ a
       }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant for aligned shapes (M, N multiples of 64; K, leading dimensions and batch
+// strides multiples of 4; 32-byte aligned bases) -- every product of the Procrustes core.
+// The kernel above stages element-wise with bounds checks (98 VGPRs + 32 AGPRs: 3-4 waves per
+// SIMD) and waits for its global loads between two barriers per K chunk: 46-58 % of the measured
+// 47 TFLOP/s fp64-MFMA ceiling.  Here each thread fetches one 4-element vector of A and of B for
+// chunk c+1 BEFORE the 16 MFMAs of chunk c, parks it in registers, and stores it to the other LDS
+// buffer afterwards: one barrier per chunk, the loads fly under the matrix work.
+// The transposes are template parameters (no runtime branches in the staging code).
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<double> { typedef double type __attribute__((ext_vector_type(4))); };
+
+// KMAJ == 1: the operand tile is contiguous along the tile dimension  -> element (k, i) = x[(k0 + k) * ld + t0 + i]
+// KMAJ == 0: the operand tile is contiguous along k                  -> element (k, i) = x[(t0 + i) * ld + k0 + k]
+template <typename T, int KMAJ>
+__device__ __forceinline__ typename Vec4<T>::type fetch4(const T* __restrict__ x, int ld, int t0, int k0, int K, int tid) {
+  typedef typename Vec4<T>::type V;
+  if (KMAJ) {
+    const int k = tid >> 4, i4 = (tid & 15) * 4;
+    if (k0 + k < K) return *reinterpret_cast<const V*>(x + (size_t)(k0 + k) * ld + t0 + i4);
+  } else {
+    const int i = tid >> 2, kq = (tid & 3) * 4;
+    if (k0 + kq < K) return *reinterpret_cast<const V*>(x + (size_t)(t0 + i) * ld + k0 + kq);
+  }
+  return (V){0, 0, 0, 0};
+}
+template <typename T, int KMAJ>
+__device__ __forceinline__ void park4(typename Vec4<T>::type v, double* __restrict__ dst, int tid) {
+  if (KMAJ) {
+    const int k = tid >> 4, i4 = (tid & 15) * 4;
+    double2* d = reinterpret_cast<double2*>(dst + k * BLD + i4);
+    d[0] = make_double2((double)v.x, (double)v.y);
+    d[1] = make_double2((double)v.z, (double)v.w);
+  } else {
+    const int i = tid >> 2, kq = (tid & 3) * 4;
+    dst[(kq + 0) * BLD + i] = (double)v.x;
+    dst[(kq + 1) * BLD + i] = (double)v.y;
+    dst[(kq + 2) * BLD + i] = (double)v.z;
+    dst[(kq + 3) * BLD + i] = (double)v.w;
+  }
+}
+
+template <typename TA, typename TB, typename TC, int TRA, int TRB>
+__global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restrict__ a, int64_t sa, int lda,
+                                                             const TB* __restrict__ b, int64_t sb, int ldb,
+                                                             TC* __restrict__ c, int64_t sc, int ldc, int M, int N,
+                                                             int K, int sym) {
+  __shared__ __align__(16) double As[2][BK * BLD];
+  __shared__ __align__(16) double Bs[2][BK * BLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  if (sym && n0 > m0) return;
+  const TA* A = a + (size_t)blockIdx.z * sa;
+  const TB* B = b + (size_t)blockIdx.z * sb;
+  TC* C = c + (size_t)blockIdx.z * sc;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // op(A) tile: TRA == 0 -> A is [M, K] (contiguous along k); TRA == 1 -> A is [K, M]
+  // op(B) tile: TRB == 0 -> B is [K, N] (contiguous along the tile dim); TRB == 1 -> B is [N, K]
+  typename Vec4<TA>::type ra = fetch4<TA, TRA>(A, lda, m0, 0, K, tid);
+  typename Vec4<TB>::type rb = fetch4<TB, 1 - TRB>(B, ldb, n0, 0, K, tid);
+  park4<TA, TRA>(ra, As[0], tid);
+  park4<TB, 1 - TRB>(rb, Bs[0], tid);
+  __syncthreads();
+  const int nchunk = (K + BK - 1) / BK;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int cur = ch & 1;
+    const bool more = ch + 1 < nchunk;
+    if (more) {
+      ra = fetch4<TA, TRA>(A, lda, m0, (ch + 1) * BK, K, tid);
+      rb = fetch4<TB, 1 - TRB>(B, ldb, n0, (ch + 1) * BK, K, tid);
+    }
+    const double* as = As[cur];
+    const double* bs = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + (lane >> 4);
+      double av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = as[kr * BLD + wm + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = bs[kr * BLD + wn + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      park4<TA, TRA>(ra, As[cur ^ 1], tid);
+      park4<TB, 1 - TRB>(rb, Bs[cur ^ 1], tid);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = m0 + wm + i * 16 + (lane >> 4) + 4 * reg;
+        const int col = n0 + wn + j * 16 + (lane & 15);
+        C[(size_t)r * ldc + col] = (TC)acc[i][j][reg];
+        if (sym && n0 != m0) C[(size_t)col * ldc + r] = (TC)acc[i][j][reg];
+      }
+}
+
+template <typename TA, typename TB, typename TC>
+static void launch_bgemm_fast(const void* a, int64_t sa, int lda, int ta, const void* b, int64_t sb, int ldb, int tb,
+                              void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, hipStream_t st) {
+  dim3 grid(N / BT, M / BT, batch);
+#define BASD_BGF(TRA, TRB)                                                                                   \
+  hipLaunchKernelGGL((bgemm_f64_fast_kernel<TA, TB, TC, TRA, TRB>), grid, dim3(256), 0, st, (const TA*)a, sa, lda, \
+                     (const TB*)b, sb, ldb, (TC*)c, sc, ldc, M, N, K, sym)
+  if (ta) { if (tb) BASD_BGF(1, 1); else BASD_BGF(1, 0); }
+  else    { if (tb) BASD_BGF(0, 1); else BASD_BGF(0, 0); }
+#undef BASD_BGF
+}
+
 template <typename TA, typename TB, typename TC>
 static void launch_bgemm(const void* a, int64_t sa, int lda, int ta, const void* b, int64_t sb, int ldb, int tb,
                          void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, hipStream_t st) {
@@ -121,7 +247,14 @@ extern "C" int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int 
   if (K <= 0 || batch > 65535) return fail(BASD_ERR_SHAPE, "bgemm_f64: bad shape batch=%d K=%d", batch, K);
   hipStream_t st = (hipStream_t)stream;
   const int key = a_dtype * 100 + b_dtype * 10 + c_dtype;
-#define BASD_BG(TA, TB, TC) launch_bgemm<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, st)
+  static const bool no_fast = getenv("BASD_BGEMM_PLAIN") != nullptr;   // debugging aid: element-wise staging only
+  const bool aligned = !no_fast && M % BT == 0 && N % BT == 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+                       a_stride % 4 == 0 && b_stride % 4 == 0 && ((uintptr_t)a & 31) == 0 && ((uintptr_t)b & 31) == 0;
+#define BASD_BG(TA, TB, TC)                                                                                          \
+  do {                                                                                                               \
+    if (aligned) launch_bgemm_fast<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, st); \
+    else launch_bgemm<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, st); \
+  } while (0)
   switch (key) {
     case 2: BASD_BG(float, float, double); break;      // f32 x f32 -> f64
     case 0: BASD_BG(float, float, float); break;
