@@ -11,6 +11,7 @@
 // that  out @ M  ==  L_p^-1 (P M)  for any M whose rows are in ORIGINAL order: no
 // gather of the right-hand sides is needed.  Columns >= rank of L_p are replaced by
 // unit columns (their rows of out are zeroed: pseudo-inverse semantics).
+#include <stdlib.h>
 #include "basd_common.h"
 
 namespace basd {
@@ -71,6 +72,122 @@ __global__ __launch_bounds__(768) void trinv_kernel(const double* __restrict__ l
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Blocked version on the fp64 matrix cores (default).  The kernel above walks the 192 columns one
+// by one (two barriers and an LDS-latency-bound dot product per column: 0.4 ms per matrix).  Here
+// L_p is held as 16 x 16 blocks and inverted block column by block column:
+//   1. X_jj = L_jj^-1 for the 12 diagonal blocks at once (one thread per column, registers),
+//   2. W_kj = L_kj X_jj for every sub-diagonal block (independent 16^3 products, one wave each),
+//   3. for j = nb-2 .. 0:   X_ij = - sum_{k=j+1..i} X_ik W_kj   (i > j; one wave per row block,
+//      v_mfma_f64_16x16x4_f64 chains), which only reads finished block columns > j of X and
+//      column j of W: 11 levels with two barriers each instead of 192 steps.
+// Same input / output contract as trinv_kernel.
+typedef double f64x4t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * 256; }
+
+// C (16x16, registers) += A (block at a_off) * B (block at b_off), blocks row-major [16][16] in LDS
+__device__ __forceinline__ f64x4t blk_mma(const double* __restrict__ X, int a_off, int b_off, f64x4t acc, int lane) {
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double av = X[a_off + lr * 16 + 4 * kk + lq];       // A[row = lane & 15][k = 4 kk + (lane >> 4)]
+    const double bv = X[b_off + (4 * kk + lq) * 16 + lr];     // B[k][col = lane & 15]
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(768) void trinv_blocked_kernel(const double* __restrict__ lw_all,
+                                                            const int32_t* __restrict__ piv_all,
+                                                            const int32_t* __restrict__ rank_all, int n,
+                                                            double* __restrict__ out_all) {
+  extern __shared__ __align__(16) double X[];          // lower block triangle, 16 x 16 row-major blocks
+  const int nb = (n + 15) >> 4;
+  double* s_rd = X + (size_t)nb * (nb + 1) / 2 * 256;  // [16 nb] reciprocal diagonal
+  int* s_piv = reinterpret_cast<int*>(s_rd + 16 * nb); // [16 nb]
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  const double* Lw = lw_all + (size_t)blockIdx.x * n * n;
+  const int32_t* piv = piv_all + (size_t)blockIdx.x * n;
+  const int rank = rank_all[blockIdx.x];
+  double* out = out_all + (size_t)blockIdx.x * n * n;
+
+  for (int i = tid; i < 16 * nb; i += nt) s_piv[i] = (i < n) ? piv[i] : 0;
+  __syncthreads();
+  // ---- gather L_p[i, k] = Lw[k * n + piv[i]] (k <= i); dead / padding columns -> identity
+  const int nblk = nb * (nb + 1) / 2;
+  for (int e = tid; e < nblk * 256; e += nt) {
+    const int b = e >> 8, r = e & 15, c = (e >> 4) & 15;   // consecutive threads: consecutive rows of a column
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+    const int bj = b - bi * (bi + 1) / 2;
+    const int i = 16 * bi + r, k = 16 * bj + c;
+    double v = (i == k) ? 1.0 : 0.0;
+    if (k < rank && i < n && k <= i) v = Lw[(size_t)k * n + s_piv[i]];
+    X[b * 256 + r * 16 + c] = v;
+  }
+  __syncthreads();
+  if (tid < 16 * nb) s_rd[tid] = 1.0 / X[blk_off(tid >> 4, tid >> 4) + (tid & 15) * 17];
+  __syncthreads();
+  // ---- 1. diagonal blocks: thread (block j, column c) solves L_jj x = e_c in registers
+  double x[16];
+  if (tid < 16 * nb) {
+    const int j = tid >> 4, c = tid & 15;
+    const double* D = X + blk_off(j, j);
+    const double* rd = s_rd + 16 * j;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double acc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = 0; m < i; ++m) acc = fma(-D[i * 16 + m], x[m], acc);
+      x[i] = (i >= c) ? acc * rd[i] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid < 16 * nb) {
+    double* D = X + blk_off(tid >> 4, tid >> 4);
+    const int c = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) D[i * 16 + c] = x[i];
+  }
+  __syncthreads();
+  // ---- 2. W_kj = L_kj X_jj, in place, one wave per block
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int b = wave; b < nblk; b += nw) {
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+    const int bj = b - bi * (bi + 1) / 2;
+    if (bi == bj) continue;                                  // uniform per wave
+    f64x4t acc = {0.0, 0.0, 0.0, 0.0};
+    acc = blk_mma(X, b * 256, blk_off(bj, bj), acc, lane);   // all operand reads precede the stores below
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) X[b * 256 + (lq + 4 * reg) * 16 + lr] = acc[reg];
+  }
+  __syncthreads();
+  // ---- 3. block columns from the right: X_ij = - sum_k X_ik W_kj
+  for (int j = nb - 2; j >= 0; --j) {
+    const int i = j + 1 + wave;
+    f64x4t acc = {0.0, 0.0, 0.0, 0.0};
+    if (i < nb) {
+      for (int k = j + 1; k <= i; ++k) acc = blk_mma(X, blk_off(i, k), blk_off(k, j), acc, lane);
+    }
+    __syncthreads();                                          // every W_kj of this column has been read
+    if (i < nb) {
+      double* D = X + blk_off(i, j);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) D[(lq + 4 * reg) * 16 + lr] = -acc[reg];
+    }
+    __syncthreads();
+  }
+  // ---- out[k, piv[c]] = X[k, c] (c <= k < rank), zero elsewhere
+  for (int e = tid; e < n * n; e += nt) {
+    const int k = e / n, c = e - k * n;
+    double v = 0.0;
+    if (c <= k && k < rank) v = X[blk_off(k >> 4, c >> 4) + (k & 15) * 16 + (c & 15)];
+    out[(size_t)k * n + s_piv[c]] = v;
+  }
+}
+
 }  // namespace basd
 
 extern "C" int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank, int batch, int n,
@@ -80,6 +197,15 @@ extern "C" int basd_trinv_f64(const double* lwork, const int32_t* piv, const int
   const size_t lds = (size_t)n * (n + 1) / 2 * 8 + (size_t)n * 4 + 64;
   if (n < 1 || lds > 160 * 1024)
     return fail(BASD_ERR_SHAPE, "trinv_f64: n=%d does not fit the LDS-resident packed triangle", n);
+  static const bool columnwise = getenv("BASD_TRINV_COLUMNWISE") != nullptr;   // debugging aid: previous kernel
+  const int nb = (n + 15) / 16;
+  const size_t lds_blk = (size_t)nb * (nb + 1) / 2 * 256 * 8 + (size_t)16 * nb * (8 + 4);
+  if (!columnwise && nb <= 12 && lds_blk <= 160 * 1024) {
+    allow_full_lds((const void*)trinv_blocked_kernel);
+    hipLaunchKernelGGL(trinv_blocked_kernel, dim3(batch), dim3(768), lds_blk, (hipStream_t)stream, lwork, piv, rank, n,
+                       out);
+    return check_launch("trinv_f64 (blocked)");
+  }
   // 4 lanes per row, rows strided by 192 per pass: two passes cover n <= 384 (v[2])
   allow_full_lds((const void*)trinv_kernel);
   hipLaunchKernelGGL(trinv_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, lwork, piv, rank, n, out);
