@@ -170,6 +170,12 @@ int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, c
                             const float* rstd, int64_t rows, int D, void* dx, float* dgamma, float* dbeta,
                             void* stream);
 
+/* Teacher attention tap (reference src/models/teacher.py:33-37 hook + src/losses/relational.py:22-27):
+ * qkv [B, T, 3, H, hd] bf16 (the packed output of a block's qkv projection, CLS token first) ->
+ * out[b, t-1] = mean_h softmax_t(bf16(q_cls . k_t) * scale), t = 1..T-1, fp32.  T <= 256, hd in {32, 64}. */
+int basd_cls_importance_bf16(const void* qkv, int B, int T, int H, int hd, float scale, float* out,
+                             void* stream);
+
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:
  *   v = b2 v + (1-b2) g^2 ; gn = g / (sqrt(v / bias_correction2) + eps) + wd * y

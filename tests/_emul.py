@@ -178,6 +178,19 @@ def wgrad_bf16(dy, x, need_bias=True, out_w=None, out_b=None):
     return dw, db
 
 
+def cls_importance_supported(t, hd):
+    return 2 <= t <= 256 and hd in (32, 64)
+
+
+def cls_importance(qkv, heads, head_dim, scale):
+    b, t, _ = qkv.shape
+    x = qkv.reshape(b, t, 3, heads, head_dim)
+    q = x[:, 0, 0].float()                                  # [B, H, hd]  CLS query
+    k = x[:, :, 1].float()                                  # [B, T, H, hd]
+    logits = torch.einsum("bhd,bthd->bht", q, k).to(torch.bfloat16).float() * scale
+    return logits.softmax(dim=-1)[:, :, 1:].mean(dim=1)
+
+
 def layernorm_supported(d):
     return d % 8 == 0 and 8 <= d <= 2048
 

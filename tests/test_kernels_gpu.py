@@ -343,3 +343,22 @@ def test_layernorm_fwd_bwd(nat, rows, D):
     # frozen layer: no parameter gradients requested
     dx2 = nat.layernorm_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, rstd, None, None)
     assert torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(5, 197, 12, 64), (3, 50, 3, 64), (2, 256, 6, 32), (4, 2, 1, 64)])
+def test_cls_importance_matches_the_attention_map(nat, B, T, H, hd):
+    """head-averaged CLS row of softmax(QK^T/sqrt(hd)) without the CLS column (teacher.py:33-37,
+    relational.py:22-27), from the packed qkv projection."""
+    g = torch.Generator().manual_seed(T + H)
+    qkv = (torch.randn(B, T, 3 * H * hd, generator=g) * 1.5).to(torch.bfloat16)
+    scale = hd ** -0.5
+    out = nat.cls_importance(qkv.cuda(), H, hd, scale).cpu()
+    x = qkv.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).float()
+    q, k = x[0], x[1]
+    logits = (q[:, :, :1] @ k.transpose(-2, -1))                     # fp32 accumulate
+    ref = (logits.to(torch.bfloat16).float() * scale).softmax(dim=-1)[:, :, 0, 1:].mean(dim=1)
+    assert out.shape == (B, T - 1)
+    # a logit that lands on a bf16 rounding boundary may round the other way (different summation order)
+    assert torch.allclose(out, ref, rtol=2e-2, atol=1e-6)
+    exact = (logits * scale).softmax(dim=-1)[:, :, 0, 1:].mean(dim=1)
+    assert float((out - exact).abs().max()) <= 1.5 * float((ref - exact).abs().max()) + 1e-6

@@ -22,6 +22,7 @@ EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
+    "basd_cls_importance_bf16",
 )
 
 
@@ -349,6 +350,22 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True, out_w:
     _check(lib().basd_wgrad_bf16(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _stream()),
            "basd_wgrad_bf16")
     return dw, db
+
+
+def cls_importance_supported(t: int, hd: int) -> bool:
+    return 2 <= t <= 256 and hd in (32, 64)
+
+
+def cls_importance(qkv: torch.Tensor, heads: int, head_dim: int, scale: float) -> torch.Tensor:
+    """qkv [B, T, 3 * heads * head_dim] bf16 (CLS token first) -> head-averaged CLS attention [B, T-1] fp32."""
+    _need_cuda(qkv)
+    assert qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 3 * heads * head_dim
+    qkv = qkv.contiguous()
+    b, t = qkv.shape[0], qkv.shape[1]
+    out = torch.empty(b, t - 1, dtype=torch.float32, device=qkv.device)
+    _check(lib().basd_cls_importance_bf16(_ptr(qkv), b, t, heads, head_dim, ctypes.c_float(scale), _ptr(out), _stream()),
+           "basd_cls_importance_bf16")
+    return out
 
 
 def layernorm_supported(d: int) -> bool:

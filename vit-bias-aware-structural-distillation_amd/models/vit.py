@@ -111,10 +111,17 @@ class Attention(nn.Module):
 
     def forward(self, x):
         b, t, c = x.shape
-        qkv = self.qkv(x).reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        qkv_flat = self.qkv(x)
+        qkv = qkv_flat.reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
         if self.tap is not None:
-            self.tap["out"] = self._importance(q, k, self.tap["has_cls"])
+            ops = get_ops() if (qkv_flat.is_cuda or is_emulated()) else None
+            if (ops is not None and self.tap["has_cls"] and qkv_flat.dtype == torch.bfloat16
+                    and ops.cls_importance_supported(t, self.head_dim)):
+                # fused tap: streams K once from the packed projection (csrc/attn_tap.hip)
+                self.tap["out"] = ops.cls_importance(qkv_flat, self.num_heads, self.head_dim, self.scale)
+            else:
+                self.tap["out"] = self._importance(q, k, self.tap["has_cls"])
         out = F.scaled_dot_product_attention(q, k, v)
         return self.proj(out.transpose(1, 2).reshape(b, t, c))
 
