@@ -166,6 +166,11 @@ int basd_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, floa
  * (fp32 atomics; pass NULL for a frozen layer).  D % 8 == 0, D <= 2048. */
 int basd_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, int64_t rows, int D,
                             float eps, void* y, float* mean, float* rstd, void* stream);
+/* Pre-norm residual step of a frozen block: sum_out = bf16(x + residual), y = LayerNorm(sum_out).
+ * mean / rstd may be NULL. */
+int basd_add_layernorm_fwd_bf16(const void* x, const void* residual, const float* gamma, const float* beta,
+                                int64_t rows, int D, float eps, void* sum_out, void* y, float* mean,
+                                float* rstd, void* stream);
 int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean,
                             const float* rstd, int64_t rows, int D, void* dx, float* dgamma, float* dbeta,
                             void* stream);

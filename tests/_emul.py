@@ -191,6 +191,12 @@ def cls_importance(qkv, heads, head_dim, scale):
     return logits.softmax(dim=-1)[:, :, 1:].mean(dim=1)
 
 
+def add_layernorm_fwd(x, residual, gamma, beta, eps):
+    s = (x.float() + residual.float()).to(torch.bfloat16)
+    y, _, _ = layernorm_fwd(s, gamma, beta, eps)
+    return s, y
+
+
 def layernorm_supported(d):
     return d % 8 == 0 and 8 <= d <= 2048
 

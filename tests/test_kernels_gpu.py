@@ -345,6 +345,20 @@ def test_layernorm_fwd_bwd(nat, rows, D):
     assert torch.equal(dx, dx2)
 
 
+@pytest.mark.parametrize("rows,D", [(1001, 768), (77, 192), (300, 1280)])
+def test_add_layernorm_equals_add_then_layernorm(nat, rows, D):
+    g = torch.Generator().manual_seed(rows * 3 + D)
+    x = (torch.randn(rows, D, generator=g) * 2.0).bfloat16().cuda()
+    r = torch.randn(rows, D, generator=g).bfloat16().cuda()
+    gamma = (torch.randn(D, generator=g) * 0.5 + 1.0).cuda()
+    beta = (torch.randn(D, generator=g) * 0.1).cuda()
+    s, y = nat.add_layernorm_fwd(x, r, gamma, beta, 1e-6)
+    s_ref = x + r                                            # bf16 add, rounded like torch's
+    y_ref, _, _ = nat.layernorm_fwd(s_ref, gamma, beta, 1e-6)
+    assert torch.equal(s, s_ref)
+    assert torch.equal(y, y_ref)
+
+
 @pytest.mark.parametrize("B,T,H,hd", [(5, 197, 12, 64), (3, 50, 3, 64), (2, 256, 6, 32), (4, 2, 1, 64)])
 def test_cls_importance_matches_the_attention_map(nat, B, T, H, hd):
     """head-averaged CLS row of softmax(QK^T/sqrt(hd)) without the CLS column (teacher.py:33-37,

@@ -22,7 +22,7 @@ EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
-    "basd_cls_importance_bf16",
+    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16",
 )
 
 
@@ -386,6 +386,22 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
                                          d, ctypes.c_float(eps), _ptr(y), _ptr(mean), _ptr(rstd), _stream()),
            "basd_layernorm_fwd_bf16")
     return y, mean, rstd
+
+
+def add_layernorm_fwd(x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    """(x + residual) rounded to bf16 and its LayerNorm: -> (sum bf16, y bf16).  Inference only (no statistics kept)."""
+    _need_cuda(x, residual, gamma, beta)
+    assert x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and x.shape == residual.shape
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    x, residual = x.contiguous(), residual.contiguous()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    s = torch.empty_like(x)
+    y = torch.empty_like(x)
+    _check(lib().basd_add_layernorm_fwd_bf16(_ptr(x), _ptr(residual), _ptr(gamma.contiguous()), _ptr(beta.contiguous()),
+                                             ctypes.c_int64(rows), d, ctypes.c_float(eps), _ptr(s), _ptr(y), None, None,
+                                             _stream()), "basd_add_layernorm_fwd_bf16")
+    return s, y
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,

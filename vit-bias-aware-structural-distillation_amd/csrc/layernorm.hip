@@ -3,16 +3,22 @@
 // Under bf16 autocast torch upcasts layer_norm inputs to fp32 (a copy in, a copy out per call) and
 // its ROCm kernel refuses bf16 activations with fp32 parameters; backward is three more kernels.
 // Here forward is one pass (x read once, y written once, mean / rstd saved) and backward is one
-// pass that also accumulates d gamma / d beta (per-thread column partials, one fp32 atomic per
+// pass that also accumulates d gamma / d beta (per-lane column partials, one fp32 atomic per
 // column per workgroup -- straight into the flat gradient buffer when the caller passes it).
 // The result equals torch's fp32 layer_norm followed by the bf16 rounding the next Linear applies.
+// The forward optionally fuses the residual add that precedes the norm in a pre-norm block
+// (s = bf16(x + r) written out, y = LN(s)): one kernel instead of add + norm for the frozen teacher.
 //
-// Layout: each thread owns 8 contiguous columns (one 16-byte load); a row is covered by
-// TPR = D / 8 threads (D % 8 == 0, D <= 2048); a 256-thread workgroup processes
-// RPB = 256 / TPR rows per iteration and grid-strides over the rows.
+// Layout: a row is owned by a GROUP of G lanes of one wave (G = 32 for D <= 256, else 64; two
+// rows per wave when G = 32) and every lane holds NCH chunks of 8 contiguous columns (one 16-byte
+// load each: chunk = lane_in_group + c * G).  Row statistics are reduced inside the wave with DPP
+// row operations and v_permlane16/32_swap: no LDS, no barrier in the row loop (the first version
+// of this kernel reduced through LDS with four barriers per row and ran at 1.9 TB/s).
 #include "basd_common.h"
 
 namespace basd {
+
+typedef unsigned int ln_u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
   const unsigned int w[4] = {v.x, v.y, v.z, v.w};
@@ -27,147 +33,210 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
   return (unsigned int)(*reinterpret_cast<unsigned short*>(&x)) |
          ((unsigned int)(*reinterpret_cast<unsigned short*>(&y)) << 16);
 }
-
-// sum over the TPR threads of a row (row groups are contiguous thread ranges) through LDS.
-// Called by EVERY thread of the workgroup (the barriers must not sit in a branch that splits a
-// wave: with D = 192 the last wave holds both worker and idle lanes); idle threads only synchronise.
-template <int NV>
-__device__ __forceinline__ void row_reduce(float (&v)[NV], float* red, int row_in_blk, int t_in_row, int tpr,
-                                           bool worker) {
-  // red: [RPB][NV][TPR] -> every thread of the row sums the TPR partials
-  if (worker) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) red[(row_in_blk * NV + k) * tpr + t_in_row] = v[k];
-  }
-  __syncthreads();
-  if (worker) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      float s = 0.f;
-      const float* p = red + (row_in_blk * NV + k) * tpr;
-      for (int j = 0; j < tpr; ++j) s += p[j];
-      v[k] = s;
-    }
-  }
-  __syncthreads();
+__device__ __forceinline__ float round_bf16(float a) {
+  __hip_bfloat16 x = __float2bfloat16(a);
+  return bf16_bits_to_f32(*reinterpret_cast<unsigned short*>(&x));
 }
 
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, int64_t rows, int D, float eps,
+// sum over the G lanes of a row group, result in every lane of the group
+template <int G>
+__device__ __forceinline__ float group_allsum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  ln_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);                                                 // rows 0+1, 2+3
+  if (G == 64) {
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  }
+  return v;
+}
+
+// FUSE_ADD: s = bf16(x + res) is written to `sum_out` and normalised; otherwise x is normalised.
+template <int G, int NCH, bool FUSE_ADD>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x,
+                                                     const unsigned short* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int64_t rows, int D, float eps, unsigned short* __restrict__ sum_out,
                                                      unsigned short* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd) {
-  extern __shared__ float red[];
-  const int tpr = D >> 3, rpb = 256 / tpr;
-  const int tid = threadIdx.x;
-  const int row_in_blk = tid / tpr, t_in_row = tid - row_in_blk * tpr;
-  const bool worker = row_in_blk < rpb;
-  float g[8], b[8];
-  if (worker) {
+  constexpr int RPW = 64 / G;                       // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lg = lane & (G - 1), sub = lane / G;
+  const int nchunk = D >> 3;
+  float g[NCH][8], b[NCH][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { g[i] = gamma[t_in_row * 8 + i]; b[i] = beta[t_in_row * 8 + i]; }
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lg + c * G;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      g[c][i] = ch < nchunk ? gamma[ch * 8 + i] : 0.f;
+      b[c][i] = ch < nchunk ? beta[ch * 8 + i] : 0.f;
+    }
   }
-  for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < rows; r0 += (int64_t)gridDim.x * rpb) {
-    const int64_t r = r0 + row_in_blk;
-    const bool live = worker && r < rows;
-    float f[8];
-    if (live) unpack8(*reinterpret_cast<const uint4*>(x + r * D + t_in_row * 8), f);
-    else {
+  const float inv_d = 1.f / (float)D;
+  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t r = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub; r < rows; r += wstride) {
+    float f[NCH][8];
+    float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) f[i] = 0.f;
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lg + c * G;
+      if (ch < nchunk) {
+        unpack8(*reinterpret_cast<const uint4*>(x + r * D + ch * 8), f[c]);
+        if (FUSE_ADD) {
+          float fr[8];
+          unpack8(*reinterpret_cast<const uint4*>(res + r * D + ch * 8), fr);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[c][i] = round_bf16(f[c][i] + fr[i]);
+          uint4 o;
+          o.x = pack2(f[c][0], f[c][1]); o.y = pack2(f[c][2], f[c][3]); o.z = pack2(f[c][4], f[c][5]); o.w = pack2(f[c][6], f[c][7]);
+          *reinterpret_cast<uint4*>(sum_out + r * D + ch * 8) = o;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[c][i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += f[c][i];
     }
-    float s[1] = {0.f};
+    // rows beyond `rows` never enter the loop, but the lanes of the other row group of this wave may
+    // have left it: the cross-lane reductions below only combine lanes of the SAME group
+    const float mu = group_allsum<G>(s) * inv_d;
+    float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[0] += f[i];
-    row_reduce<1>(s, red, row_in_blk, t_in_row, tpr, worker);
-    const float mu = s[0] / (float)D;
-    float q[1] = {0.f};
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lg + c * G;
+      if (ch < nchunk) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const float d = f[i] - mu; q[0] = fmaf(d, d, q[0]); }   // two-pass variance
-    row_reduce<1>(q, red, row_in_blk, t_in_row, tpr, worker);
-    const float rs = rsqrtf(q[0] / (float)D + eps);
-    if (live) {
-      float o[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = fmaf((f[i] - mu) * rs, g[i], b[i]);
-      uint4 out;
-      out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
-      *reinterpret_cast<uint4*>(y + r * D + t_in_row * 8) = out;
-      if (t_in_row == 0) { mean[r] = mu; rstd[r] = rs; }
+        for (int i = 0; i < 8; ++i) { const float d = f[c][i] - mu; q = fmaf(d, d, q); }   // two-pass variance
+      }
     }
+    const float rs = rsqrtf(group_allsum<G>(q) * inv_d + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lg + c * G;
+      if (ch < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf((f[c][i] - mu) * rs, g[c][i], b[c][i]);
+        uint4 out;
+        out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(y + r * D + ch * 8) = out;
+      }
+    }
+    if (lg == 0 && mean != nullptr) { mean[r] = mu; rstd[r] = rs; }
   }
 }
 
+template <int G, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int64_t rows, int D,
                                                      unsigned short* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta) {
-  extern __shared__ float red[];
-  const int tpr = D >> 3, rpb = 256 / tpr;
-  const int tid = threadIdx.x;
-  const int row_in_blk = tid / tpr, t_in_row = tid - row_in_blk * tpr;
-  const bool worker = row_in_blk < rpb;
-  float g[8], dg[8], db[8];
+  extern __shared__ float acc[];                    // [2][D] column partials of the workgroup
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lg = lane & (G - 1), sub = lane / G;
+  const int nchunk = D >> 3;
+  float g[NCH][8], dg[NCH][8], db[NCH][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { g[i] = worker ? gamma[t_in_row * 8 + i] : 0.f; dg[i] = 0.f; db[i] = 0.f; }
-  for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < rows; r0 += (int64_t)gridDim.x * rpb) {
-    const int64_t r = r0 + row_in_blk;
-    const bool live = worker && r < rows;
-    float fx[8], fdy[8], xh[8], gg[8];
-    float mu = 0.f, rs = 0.f;
-    if (live) {
-      unpack8(*reinterpret_cast<const uint4*>(x + r * D + t_in_row * 8), fx);
-      unpack8(*reinterpret_cast<const uint4*>(dy + r * D + t_in_row * 8), fdy);
-      mu = mean[r]; rs = rstd[r];
-    } else {
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lg + c * G;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { fx[i] = 0.f; fdy[i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { g[c][i] = ch < nchunk ? gamma[ch * 8 + i] : 0.f; dg[c][i] = 0.f; db[c][i] = 0.f; }
+  }
+  const float inv_d = 1.f / (float)D;
+  const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t r = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub; r < rows; r += wstride) {
+    const float mu = mean[r], rs = rstd[r];
+    float xh[NCH][8], gg[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lg + c * G;
+      if (ch < nchunk) {
+        float fx[8], fdy[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + r * D + ch * 8), fx);
+        unpack8(*reinterpret_cast<const uint4*>(dy + r * D + ch * 8), fdy);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xh[c][i] = (fx[i] - mu) * rs;
+          gg[c][i] = fdy[i] * g[c][i];
+          s1 += gg[c][i];
+          s2 = fmaf(gg[c][i], xh[c][i], s2);
+          dg[c][i] = fmaf(fdy[i], xh[c][i], dg[c][i]);
+          db[c][i] += fdy[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xh[c][i] = 0.f; gg[c][i] = 0.f; }
+      }
     }
-    float s[2] = {0.f, 0.f};
+    const float m1 = group_allsum<G>(s1) * inv_d, m2 = group_allsum<G>(s2) * inv_d;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      xh[i] = (fx[i] - mu) * rs;
-      gg[i] = fdy[i] * g[i];
-      s[0] += gg[i];
-      s[1] = fmaf(gg[i], xh[i], s[1]);
-      dg[i] = fmaf(fdy[i], xh[i], dg[i]);
-      db[i] += fdy[i];
-    }
-    row_reduce<2>(s, red, row_in_blk, t_in_row, tpr, worker);
-    if (live) {
-      const float m1 = s[0] / (float)D, m2 = s[1] / (float)D;
-      float o[8];
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lg + c * G;
+      if (ch < nchunk) {
+        float o[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = rs * (gg[i] - m1 - xh[i] * m2);
-      uint4 out;
-      out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
-      *reinterpret_cast<uint4*>(dx + r * D + t_in_row * 8) = out;
+        for (int i = 0; i < 8; ++i) o[i] = rs * (gg[c][i] - m1 - xh[c][i] * m2);
+        uint4 out;
+        out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(dx + r * D + ch * 8) = out;
+      }
     }
   }
-  // column partials: combine the RPB row groups of the workgroup in LDS, then one atomic per column
+  // column partials: combine the row groups of the workgroup in LDS, then one atomic per column
   if (dgamma != nullptr) {
-    float* acc = red;                                  // [2][D]
-    for (int i = tid; i < 2 * D; i += 256) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) acc[i] = 0.f;
     __syncthreads();
-    if (worker) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        atomicAdd(&acc[t_in_row * 8 + i], dg[i]);
-        atomicAdd(&acc[D + t_in_row * 8 + i], db[i]);
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lg + c * G;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          atomicAdd(&acc[ch * 8 + i], dg[c][i]);
+          atomicAdd(&acc[D + ch * 8 + i], db[c][i]);
+        }
       }
     }
     __syncthreads();
-    for (int i = tid; i < D; i += 256) {
+    for (int i = threadIdx.x; i < D; i += 256) {
       atomicAdd(&dgamma[i], acc[i]);
       atomicAdd(&dbeta[i], acc[D + i]);
     }
   }
 }
 
-static int ln_grid(int64_t rows, int rpb) {
-  int64_t g = (rows + rpb - 1) / rpb;
-  if (g > 1024) g = 1024;
+static int ln_grid(int64_t rows, int rows_per_wg, int cap = 2048) {
+  int64_t g = (rows + rows_per_wg - 1) / rows_per_wg;
+  if (g > cap) g = cap;
   return (int)(g < 1 ? 1 : g);
+}
+
+template <bool FUSE>
+static int launch_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, int64_t rows, int D,
+                         float eps, void* sum_out, void* y, float* mean, float* rstd, hipStream_t st) {
+  const int nchunk = D / 8;
+  const unsigned short* xp = (const unsigned short*)x;
+  const unsigned short* rp = (const unsigned short*)res;
+  unsigned short* sp = (unsigned short*)sum_out;
+  unsigned short* yp = (unsigned short*)y;
+#define BASD_LN_FWD(G, NCH)                                                                                   \
+  hipLaunchKernelGGL((ln_fwd_kernel<G, NCH, FUSE>), dim3(ln_grid(rows, 4 * (64 / G))), dim3(256), 0, st, xp, rp, \
+                     gamma, beta, rows, D, eps, sp, yp, mean, rstd)
+  if (nchunk <= 32) BASD_LN_FWD(32, 1);
+  else if (nchunk <= 64) BASD_LN_FWD(64, 1);
+  else if (nchunk <= 128) BASD_LN_FWD(64, 2);
+  else if (nchunk <= 192) BASD_LN_FWD(64, 3);
+  else BASD_LN_FWD(64, 4);
+#undef BASD_LN_FWD
+  return check_launch(FUSE ? "add_layernorm_fwd_bf16" : "layernorm_fwd_bf16");
 }
 
 }  // namespace basd
@@ -177,11 +246,17 @@ extern "C" int basd_layernorm_fwd_bf16(const void* x, const float* gamma, const 
   using namespace basd;
   if (rows <= 0) return BASD_OK;
   if (D % 8 || D < 8 || D > 2048) return fail(BASD_ERR_SHAPE, "layernorm_fwd_bf16: D %% 8 != 0 or D > 2048 (%d)", D);
-  const int tpr = D / 8, rpb = 256 / tpr;
-  const size_t lds = (size_t)rpb * 2 * tpr * 4 + 64;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows, rpb)), dim3(256), lds, (hipStream_t)stream,
-                     (const unsigned short*)x, gamma, beta, rows, D, eps, (unsigned short*)y, mean, rstd);
-  return check_launch("layernorm_fwd_bf16");
+  return launch_ln_fwd<false>(x, nullptr, gamma, beta, rows, D, eps, nullptr, y, mean, rstd, (hipStream_t)stream);
+}
+
+extern "C" int basd_add_layernorm_fwd_bf16(const void* x, const void* residual, const float* gamma, const float* beta,
+                                           int64_t rows, int D, float eps, void* sum_out, void* y, float* mean,
+                                           float* rstd, void* stream) {
+  using namespace basd;
+  if (rows <= 0) return BASD_OK;
+  if (D % 8 || D < 8 || D > 2048) return fail(BASD_ERR_SHAPE, "add_layernorm_fwd_bf16: D %% 8 != 0 or D > 2048 (%d)", D);
+  if (residual == nullptr || sum_out == nullptr) return fail(BASD_ERR_SHAPE, "add_layernorm_fwd_bf16: null residual / sum_out");
+  return launch_ln_fwd<true>(x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, (hipStream_t)stream);
 }
 
 extern "C" int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean,
@@ -190,12 +265,18 @@ extern "C" int basd_layernorm_bwd_bf16(const void* dy, const void* x, const floa
   using namespace basd;
   if (rows <= 0) return BASD_OK;
   if (D % 8 || D < 8 || D > 2048) return fail(BASD_ERR_SHAPE, "layernorm_bwd_bf16: D %% 8 != 0 or D > 2048 (%d)", D);
-  const int tpr = D / 8, rpb = 256 / tpr;
-  size_t lds = (size_t)rpb * 2 * tpr * 4;
-  if (lds < (size_t)2 * D * 4) lds = (size_t)2 * D * 4;
-  lds += 64;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid(rows, rpb)), dim3(256), lds, (hipStream_t)stream,
-                     (const unsigned short*)dy, (const unsigned short*)x, gamma, mean, rstd, rows, D,
-                     (unsigned short*)dx, dgamma, dbeta);
+  const int nchunk = D / 8;
+  const size_t lds = (size_t)2 * D * 4;
+  hipStream_t st = (hipStream_t)stream;
+#define BASD_LN_BWD(G, NCH)                                                                                       \
+  hipLaunchKernelGGL((ln_bwd_kernel<G, NCH>), dim3(ln_grid(rows, 4 * (64 / G) * 4, 1024)), dim3(256), lds, st,      \
+                     (const unsigned short*)dy, (const unsigned short*)x, gamma, mean, rstd, rows, D,               \
+                     (unsigned short*)dx, dgamma, dbeta)
+  if (nchunk <= 32) BASD_LN_BWD(32, 1);
+  else if (nchunk <= 64) BASD_LN_BWD(64, 1);
+  else if (nchunk <= 128) BASD_LN_BWD(64, 2);
+  else if (nchunk <= 192) BASD_LN_BWD(64, 3);
+  else BASD_LN_BWD(64, 4);
+#undef BASD_LN_BWD
   return check_launch("layernorm_bwd_bf16");
 }

@@ -84,10 +84,17 @@ class MixedLayerNorm(nn.LayerNorm):
     one-kernel backward.  Other inputs (fp32 activations, CPU) take the stock path."""
 
     def forward(self, x):
+        pre = getattr(x, "_basd_prenorm", None)
+        if pre is not None and pre[0] is self and not torch.is_grad_enabled():
+            return pre[1]               # already produced by the fused residual-add + norm of the previous step
         if (x.dtype == torch.bfloat16 and (x.is_cuda or is_emulated()) and self.elementwise_affine
                 and get_ops().layernorm_supported(x.shape[-1])):
             return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
+
+    def fused_add(self, x, residual):
+        """(x + residual, LayerNorm(x + residual)) in one kernel; inference only."""
+        return get_ops().add_layernorm_fwd(x, residual, self.weight.detach().float(), self.bias.detach().float(), self.eps)
 
 
 class LayerScale(nn.Module):
@@ -160,7 +167,26 @@ class Block(nn.Module):
         self.ls2 = LayerScale(dim, init_values) if init_values else nn.Identity()
         self.drop_path2 = DropPath(drop_path)
 
+        self._next_norm = []            # [norm that consumes this block's output]; set by the model, not a submodule
+
+    def _fused_inference(self, x) -> bool:
+        """frozen pre-norm block on bf16 activations: the residual adds fuse into the following norms"""
+        return (not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and (x.is_cuda or is_emulated())
+                and isinstance(self.ls1, nn.Identity) and isinstance(self.ls2, nn.Identity)
+                and (not self.training or (self.drop_path1.p == 0.0 and self.drop_path2.p == 0.0))
+                and self.norm2.elementwise_affine and get_ops().layernorm_supported(x.shape[-1]))
+
     def forward(self, x):
+        if self._fused_inference(x):
+            a = self.attn(self.norm1(x))
+            x, z = self.norm2.fused_add(x, a)
+            m = self.mlp(z)
+            nxt = self._next_norm[0] if self._next_norm else None
+            if nxt is None or not nxt.elementwise_affine:
+                return x + m
+            out, zn = nxt.fused_add(x, m)
+            out._basd_prenorm = (nxt, zn)
+            return out
         x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
         return x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
 
@@ -196,6 +222,8 @@ class VisionTransformer(nn.Module):
         self.blocks = nn.ModuleList([
             Block(embed_dim, num_heads, mlp_ratio, dpr[i], init_values) for i in range(depth)])
         self.norm = MixedLayerNorm(embed_dim, eps=1e-6)
+        for i, blk in enumerate(self.blocks):
+            blk._next_norm.append(self.blocks[i + 1].norm1 if i + 1 < depth else self.norm)
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         self.grad_checkpointing = False
         if self.cls_token is not None:
