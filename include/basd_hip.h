@@ -175,6 +175,14 @@ int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, c
                             const float* rstd, int64_t rows, int D, void* dx, float* dgamma, float* dbeta,
                             void* stream);
 
+/* Row epilogue of the Procrustes backward (reference src/losses/relational.py:22-45 differentiated):
+ * r [rows, D] = W - (other side) G^T as left by the GEMM, w [rows, D] the weighted centred tokens,
+ * a [rows] the normalised importance, gl [rows / rows_per_batch] the incoming gradient per sample ->
+ *   out[row, :] = 2 gl sqrt(a[row]) r[row, :]   (fp32, may alias r, or bf16)
+ *   rowdot[row] = 2 gl sum_d r[row, d] w[row, d].          D % 4 == 0. */
+int basd_procrustes_bwd_rows(const float* r, const float* w, const float* a, const float* gl, int64_t rows,
+                             int rows_per_batch, int D, void* out, int out_dtype, float* rowdot, void* stream);
+
 /* Teacher attention tap (reference src/models/teacher.py:33-37 hook + src/losses/relational.py:22-27):
  * qkv [B, T, 3, H, hd] bf16 (the packed output of a block's qkv projection, CLS token first) ->
  * out[b, t-1] = mean_h softmax_t(bf16(q_cls . k_t) * scale), t = 1..T-1, fp32.  T <= 256, hd in {32, 64}. */

@@ -109,7 +109,7 @@ def mix_grad_dots(layers, g):
     return torch.einsum("e...,l...->el", g.double(), st)
 
 
-def procrustes_prep(s, t, imp):
+def procrustes_prep(s, t, imp, out=None):
     from oracle.basd_oracle import resample_linear
     s, t, imp = s.float(), t.float(), imp.float()
     n_s = s.shape[1]
@@ -121,7 +121,21 @@ def procrustes_prep(s, t, imp):
     s_w = wc.sqrt() * (s - (wc * s).sum(1, keepdim=True))
     t_w = wc.sqrt() * (t - (wc * t).sum(1, keepdim=True))
     tr = torch.stack([(s_w.double() ** 2).sum((1, 2)), (t_w.double() ** 2).sum((1, 2))], dim=1).float()
+    if out is not None:
+        for o, v in zip(out, (s_w, t_w, a, tr)):
+            o.copy_(v)
+        return out
     return s_w.contiguous(), t_w.contiguous(), a, tr
+
+
+def procrustes_bwd_rows(r, w, a, gl, out_dtype=torch.float32):
+    c2 = 2.0 * gl.reshape(-1, 1)
+    rowdot = c2 * (r * w).sum(-1)
+    scaled = (c2 * a.sqrt()).unsqueeze(-1) * r
+    if out_dtype == torch.float32:
+        r.copy_(scaled)
+        return r, rowdot
+    return scaled.to(out_dtype), rowdot
 
 
 def sf_adamw_step(y, g, z, v, *, lr, beta1, beta2, eps, weight_decay, ckp1, bias_correction2):

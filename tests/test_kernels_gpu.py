@@ -376,3 +376,19 @@ def test_cls_importance_matches_the_attention_map(nat, B, T, H, hd):
     assert torch.allclose(out, ref, rtol=2e-2, atol=1e-6)
     exact = (logits * scale).softmax(dim=-1)[:, :, 0, 1:].mean(dim=1)
     assert float((out - exact).abs().max()) <= 1.5 * float((ref - exact).abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("B,N,D,dt", [(6, 196, 768, torch.float32), (5, 49, 192, torch.bfloat16), (3, 7, 4, torch.float32)])
+def test_procrustes_bwd_rows(nat, B, N, D, dt):
+    g = torch.Generator().manual_seed(B * N + D)
+    r = torch.randn(B, N, D, generator=g)
+    w = torch.randn(B, N, D, generator=g)
+    a = torch.rand(B, N, generator=g) + 0.01
+    gl = torch.randn(B, generator=g)
+    want = (2.0 * gl.double().view(B, 1, 1) * a.double().sqrt().unsqueeze(-1) * r.double())
+    want_dot = 2.0 * gl.double().view(B, 1) * (r.double() * w.double()).sum(-1)
+    out, dot = nat.procrustes_bwd_rows(r.cuda(), w.cuda(), a.cuda(), gl.cuda(), out_dtype=dt)
+    tol = 1e-6 if dt == torch.float32 else 8e-3
+    assert out.dtype == dt
+    assert torch.allclose(out.cpu().double(), want, rtol=tol, atol=tol * float(want.abs().max()))
+    assert torch.allclose(dot.cpu().double(), want_dot, rtol=1e-5, atol=1e-5 * float(want_dot.abs().max()))

@@ -22,7 +22,7 @@ EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
-    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16",
+    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows",
 )
 
 
@@ -260,9 +260,9 @@ def mix_grad_dots(layers: list[torch.Tensor], g: torch.Tensor) -> torch.Tensor:
     return dots
 
 
-def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor):
+def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor, out=None):
     """s [B,N_s,D_s] (f32/bf16, batch-strided view allowed), t [B,N_t,D_t] f32, imp [B,N_t] f32
-    -> s_w, t_w, a, tr[B,2]."""
+    -> s_w, t_w, a, tr[B,2]  (written into ``out`` = (s_w, t_w, a, tr) when given: contiguous fp32 views)."""
     _need_cuda(s, t, imp)
     if not (s[0].is_contiguous() and s.data_ptr() % 16 == 0):
         s = s.contiguous()
@@ -271,14 +271,36 @@ def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor):
     B, N_s, D_s = s.shape
     _, N_t, D_t = t.shape
     dev = s.device
-    s_w = torch.empty(B, N_s, D_s, dtype=torch.float32, device=dev)
-    t_w = torch.empty(B, N_s, D_t, dtype=torch.float32, device=dev)
-    a = torch.empty(B, N_s, dtype=torch.float32, device=dev)
-    tr = torch.empty(B, 2, dtype=torch.float32, device=dev)
+    if out is None:
+        s_w = torch.empty(B, N_s, D_s, dtype=torch.float32, device=dev)
+        t_w = torch.empty(B, N_s, D_t, dtype=torch.float32, device=dev)
+        a = torch.empty(B, N_s, dtype=torch.float32, device=dev)
+        tr = torch.empty(B, 2, dtype=torch.float32, device=dev)
+    else:
+        s_w, t_w, a, tr = out
+        assert s_w.shape == (B, N_s, D_s) and t_w.shape == (B, N_s, D_t) and a.shape == (B, N_s) and tr.shape == (B, 2)
+        for o in out:
+            assert o.dtype == torch.float32 and o.is_contiguous()
     _check(lib().basd_procrustes_prep(_ptr(s), _dtype_code(s), ctypes.c_int64(s.stride(0)), _ptr(t), _ptr(imp), B, N_s,
                                       N_t, D_s, D_t, _ptr(s_w), _ptr(t_w), _ptr(a), _ptr(tr), _stream()),
            "basd_procrustes_prep")
     return s_w, t_w, a, tr
+
+
+def procrustes_bwd_rows(r: torch.Tensor, w: torch.Tensor, a: torch.Tensor, gl: torch.Tensor, out_dtype=torch.float32):
+    """r, w [B, N, D] fp32, a [B, N], gl [B] -> (2 gl sqrt(a) r  [B, N, D] in out_dtype, 2 gl <r, w>_d  [B, N]).
+    With out_dtype fp32 the result overwrites ``r``."""
+    _need_cuda(r, w, a, gl)
+    for t_ in (r, w, a, gl):
+        assert t_.dtype == torch.float32 and t_.is_contiguous()
+    B, N, D = r.shape
+    assert w.shape == r.shape and a.shape == (B, N) and gl.numel() == B
+    out = r if out_dtype == torch.float32 else torch.empty(B, N, D, dtype=out_dtype, device=r.device)
+    rowdot = torch.empty(B, N, dtype=torch.float32, device=r.device)
+    code = DTYPE_F32 if out_dtype == torch.float32 else DTYPE_BF16
+    _check(lib().basd_procrustes_bwd_rows(_ptr(r), _ptr(w), _ptr(a), _ptr(gl), ctypes.c_int64(B * N), N, D, _ptr(out),
+                                          code, _ptr(rowdot), _stream()), "basd_procrustes_bwd_rows")
+    return out, rowdot
 
 
 def sf_adamw_step(y, g, z, v, *, lr, beta1, beta2, eps, weight_decay, ckp1, bias_correction2) -> None:

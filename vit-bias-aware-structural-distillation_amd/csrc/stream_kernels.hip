@@ -141,6 +141,43 @@ __global__ __launch_bounds__(256) void mix_grad_dots_kernel(LayerPtrs layers, in
   for (int i = threadIdx.x; i < E * L; i += blockDim.x) atomicAdd(&dots[i], s_acc[i]);
 }
 
+// Procrustes backward, row epilogue: R = W - (other side) G^T was formed by the GEMM (beta = 1);
+// here  out[row, :] = 2 gl sqrt(a[row]) R[row, :]   (the gradient w.r.t. the raw tokens) and
+// rowdot[row] = 2 gl sum_d R[row, d] W[row, d]        (the part of d loss / d a this side owns)
+// in ONE pass over R and W (torch needed five elementwise passes over the [E*B, N, D_t] tensors).
+// One wave per row; out may alias r (fp32) or be a bf16 buffer.
+template <typename TO>
+__global__ __launch_bounds__(256) void procrustes_bwd_rows_kernel(const float* __restrict__ r, const float* __restrict__ w,
+                                                                  const float* __restrict__ a, const float* __restrict__ gl,
+                                                                  int64_t rows, int rows_per_batch, int D, TO* out,
+                                                                  float* __restrict__ rowdot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float c2 = 2.f * gl[row / rows_per_batch];
+    const float c = c2 * sqrtf(a[row]);
+    const float4* r4 = reinterpret_cast<const float4*>(r + row * D);
+    const float4* w4 = reinterpret_cast<const float4*>(w + row * D);
+    float dot = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+      const float4 rv = r4[q], wv = w4[q];
+      dot = fmaf(rv.x, wv.x, fmaf(rv.y, wv.y, fmaf(rv.z, wv.z, fmaf(rv.w, wv.w, dot))));
+      if constexpr (sizeof(TO) == 4) {
+        reinterpret_cast<float4*>(out + row * D)[q] = make_float4(c * rv.x, c * rv.y, c * rv.z, c * rv.w);
+      } else {
+        __hip_bfloat16 b0 = __float2bfloat16(c * rv.x), b1 = __float2bfloat16(c * rv.y);
+        __hip_bfloat16 b2 = __float2bfloat16(c * rv.z), b3 = __float2bfloat16(c * rv.w);
+        uint2 o;
+        o.x = (unsigned int)(*reinterpret_cast<unsigned short*>(&b0)) | ((unsigned int)(*reinterpret_cast<unsigned short*>(&b1)) << 16);
+        o.y = (unsigned int)(*reinterpret_cast<unsigned short*>(&b2)) | ((unsigned int)(*reinterpret_cast<unsigned short*>(&b3)) << 16);
+        reinterpret_cast<uint2*>(out + row * D)[q] = o;
+      }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) rowdot[row] = c2 * dot;
+  }
+}
+
 // one workgroup per sample
 template <typename TS>
 __global__ __launch_bounds__(512) void procrustes_prep_kernel(
@@ -376,4 +413,24 @@ extern "C" int basd_procrustes_prep(const void* s, int s_dtype, int64_t s_batch_
     return fail(BASD_ERR_DTYPE, "procrustes_prep: dtype %d", s_dtype);
   }
   return check_launch("procrustes_prep");
+}
+
+extern "C" int basd_procrustes_bwd_rows(const float* r, const float* w, const float* a, const float* gl, int64_t rows,
+                                        int rows_per_batch, int D, void* out, int out_dtype, float* rowdot,
+                                        void* stream) {
+  using namespace basd;
+  if (rows <= 0) return BASD_OK;
+  if (D < 4 || D % 4 || rows_per_batch < 1) return fail(BASD_ERR_SHAPE, "procrustes_bwd_rows: D=%d rows_per_batch=%d", D, rows_per_batch);
+  int64_t grid = (rows + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == BASD_DTYPE_F32)
+    hipLaunchKernelGGL(procrustes_bwd_rows_kernel<float>, dim3((int)grid), dim3(256), 0, st, r, w, a, gl, rows,
+                       rows_per_batch, D, (float*)out, rowdot);
+  else if (out_dtype == BASD_DTYPE_BF16)
+    hipLaunchKernelGGL(procrustes_bwd_rows_kernel<unsigned short>, dim3((int)grid), dim3(256), 0, st, r, w, a, gl, rows,
+                       rows_per_batch, D, (unsigned short*)out, rowdot);
+  else
+    return fail(BASD_ERR_DTYPE, "procrustes_bwd_rows: out dtype %d", out_dtype);
+  return check_launch("procrustes_bwd_rows");
 }

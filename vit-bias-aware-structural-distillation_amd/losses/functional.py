@@ -258,11 +258,14 @@ class _ProcrustesFn(torch.autograd.Function):
         ops = get_ops()
         E = len(students)
         n_s, n_t = students[0].shape[1], t_all.shape[2]
-        sws, tws, a_s, trs = [], [], [], []
+        b, d_s, d_t, dev = students[0].shape[0], students[0].shape[2], t_all.shape[3], t_all.device
+        s_w = torch.empty(E * b, n_s, d_s, dtype=torch.float32, device=dev)                    # [E*B, ...]
+        t_w = torch.empty(E * b, n_s, d_t, dtype=torch.float32, device=dev)
+        a = torch.empty(E * b, n_s, dtype=torch.float32, device=dev)
+        tr = torch.empty(E * b, 2, dtype=torch.float32, device=dev)
         for i in range(E):
-            s_w, t_w, a, tr = ops.procrustes_prep(students[i], t_all[i], imp_all[i])
-            sws.append(s_w); tws.append(t_w); a_s.append(a); trs.append(tr)
-        s_w, t_w, a, tr = torch.cat(sws), torch.cat(tws), torch.cat(a_s), torch.cat(trs)     # [E*B, ...]
+            sl = slice(i * b, (i + 1) * b)
+            ops.procrustes_prep(students[i], t_all[i], imp_all[i], out=(s_w[sl], t_w[sl], a[sl], tr[sl]))
         nuc, g = _polar_of_cross(s_w, t_w)
         ctx.save_for_backward(s_w, t_w, a, g, imp_all)
         ctx.n_t, ctx.E = n_t, E
@@ -274,13 +277,15 @@ class _ProcrustesFn(torch.autograd.Function):
         s_w, t_w, a, g, imp_all = ctx.saved_tensors
         E = ctx.E
         n_s, n_t = s_w.shape[1], ctx.n_t
-        gl = g_loss.float().reshape(-1, 1, 1)
-        g_sw = 2.0 * gl * (s_w - t_w @ g.transpose(1, 2))
-        g_tw = 2.0 * gl * (t_w - s_w @ g)
-        root = a.sqrt().unsqueeze(-1)
-        g_s = (root * g_sw).to(ctx.s_dtype)
-        g_t = root * g_tw
-        g_a = ((g_sw * s_w).sum(-1) + (g_tw * t_w).sum(-1)) / (2.0 * a)
+        ops = get_ops()
+        gl = g_loss.float().reshape(-1).contiguous()
+        # R = W - (other side) G^T in the GEMM epilogue (beta = 1); scaling by 2 gl sqrt(a) and the row
+        # dots <R, W> that make up d loss / d a in one fused pass per side
+        r_s = torch.baddbmm(s_w, t_w, g.transpose(1, 2), beta=1.0, alpha=-1.0)
+        r_t = torch.baddbmm(t_w, s_w, g, beta=1.0, alpha=-1.0)
+        g_s, dot_s = ops.procrustes_bwd_rows(r_s, s_w, a, gl, out_dtype=ctx.s_dtype)
+        g_t, dot_t = ops.procrustes_bwd_rows(r_t, t_w, a, gl, out_dtype=torch.float32)
+        g_a = (dot_s + dot_t) / (2.0 * a)
         imp = imp_all.float().reshape(-1, n_t)
         if n_t != n_s:
             r = resample_matrix(n_t, n_s, s_w.device)                  # [n_s, n_t]

@@ -38,9 +38,19 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.p == 0.0 or not self.training:
             return x
+        return x * self.scaled_mask(x)
+
+    def scaled_mask(self, x):
+        """per-sample keep mask already divided by the keep probability (timm drop_path, scale_by_keep)"""
         keep = 1.0 - self.p
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return x * mask / keep
+        return mask / keep
+
+    def add_to(self, residual, x):
+        """residual + drop_path(x) in one elementwise kernel (addcmul) instead of mul, div and add"""
+        if self.p == 0.0 or not self.training:
+            return residual + x
+        return torch.addcmul(residual, x, self.scaled_mask(x))
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -187,8 +197,8 @@ class Block(nn.Module):
             out, zn = nxt.fused_add(x, m)
             out._basd_prenorm = (nxt, zn)
             return out
-        x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
-        return x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
+        x = self.drop_path1.add_to(x, self.ls1(self.attn(self.norm1(x))))
+        return self.drop_path2.add_to(x, self.ls2(self.mlp(self.norm2(x))))
 
 
 class PatchEmbed(nn.Module):
