@@ -176,11 +176,11 @@ int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, c
                             void* stream);
 
 /* Row epilogue of the Procrustes backward (reference src/losses/relational.py:22-45 differentiated):
- * r [rows, D] = W - (other side) G^T as left by the GEMM, w [rows, D] the weighted centred tokens,
+ * p [rows, D] = (other side) G^T from the GEMM, w [rows, D] the weighted centred tokens, R = w - p,
  * a [rows] the normalised importance, gl [rows / rows_per_batch] the incoming gradient per sample ->
- *   out[row, :] = 2 gl sqrt(a[row]) r[row, :]   (fp32, may alias r, or bf16)
- *   rowdot[row] = 2 gl sum_d r[row, d] w[row, d].          D % 4 == 0. */
-int basd_procrustes_bwd_rows(const float* r, const float* w, const float* a, const float* gl, int64_t rows,
+ *   out[row, :] = 2 gl sqrt(a[row]) R[row, :]   (fp32, may alias p, or bf16)
+ *   rowdot[row] = 2 gl sum_d R[row, d] w[row, d].          D % 4 == 0. */
+int basd_procrustes_bwd_rows(const float* p, const float* w, const float* a, const float* gl, int64_t rows,
                              int rows_per_batch, int D, void* out, int out_dtype, float* rowdot, void* stream);
 
 /* Teacher attention tap (reference src/models/teacher.py:33-37 hook + src/losses/relational.py:22-27):

@@ -130,8 +130,9 @@ def procrustes_prep(s, t, imp, out=None):
 
 def procrustes_bwd_rows(r, w, a, gl, out_dtype=torch.float32):
     c2 = 2.0 * gl.reshape(-1, 1)
-    rowdot = c2 * (r * w).sum(-1)
-    scaled = (c2 * a.sqrt()).unsqueeze(-1) * r
+    res = w - r
+    rowdot = c2 * (res * w).sum(-1)
+    scaled = (c2 * a.sqrt()).unsqueeze(-1) * res
     if out_dtype == torch.float32:
         r.copy_(scaled)
         return r, rowdot

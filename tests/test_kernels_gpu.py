@@ -385,8 +385,9 @@ def test_procrustes_bwd_rows(nat, B, N, D, dt):
     w = torch.randn(B, N, D, generator=g)
     a = torch.rand(B, N, generator=g) + 0.01
     gl = torch.randn(B, generator=g)
-    want = (2.0 * gl.double().view(B, 1, 1) * a.double().sqrt().unsqueeze(-1) * r.double())
-    want_dot = 2.0 * gl.double().view(B, 1) * (r.double() * w.double()).sum(-1)
+    res = w.double() - r.double()
+    want = (2.0 * gl.double().view(B, 1, 1) * a.double().sqrt().unsqueeze(-1) * res)
+    want_dot = 2.0 * gl.double().view(B, 1) * (res * w.double()).sum(-1)
     out, dot = nat.procrustes_bwd_rows(r.cuda(), w.cuda(), a.cuda(), gl.cuda(), out_dtype=dt)
     tol = 1e-6 if dt == torch.float32 else 8e-3
     assert out.dtype == dt

@@ -288,8 +288,8 @@ def procrustes_prep(s: torch.Tensor, t: torch.Tensor, imp: torch.Tensor, out=Non
 
 
 def procrustes_bwd_rows(r: torch.Tensor, w: torch.Tensor, a: torch.Tensor, gl: torch.Tensor, out_dtype=torch.float32):
-    """r, w [B, N, D] fp32, a [B, N], gl [B] -> (2 gl sqrt(a) r  [B, N, D] in out_dtype, 2 gl <r, w>_d  [B, N]).
-    With out_dtype fp32 the result overwrites ``r``."""
+    """r = (other side) G^T, w [B, N, D] fp32, a [B, N], gl [B] -> with R = w - r:
+    (2 gl sqrt(a) R  [B, N, D] in out_dtype, 2 gl <R, w>_d  [B, N]).  With out_dtype fp32 the result overwrites ``r``."""
     _need_cuda(r, w, a, gl)
     for t_ in (r, w, a, gl):
         assert t_.dtype == torch.float32 and t_.is_contiguous()

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
                                                      const float* __restrict__ rstd, int64_t rows, int D,
                                                      unsigned short* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta) {
-  extern __shared__ float acc[];                    // [2][D] column partials of the workgroup
+  extern __shared__ float acc[];                    // [4 waves][2][D] column partials
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lg = lane & (G - 1), sub = lane / G;
@@ -190,25 +190,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
       }
     }
   }
-  // column partials: combine the row groups of the workgroup in LDS, then one atomic per column
+  // column partials: the two row groups of a wave (G = 32) combine through v_permlane32_swap, the four
+  // waves through their own LDS rows (plain stores: LDS float atomics serialise per lane, 14 us of a
+  // 42 us call), then one global atomic per column per workgroup
   if (dgamma != nullptr) {
-    for (int i = threadIdx.x; i < 2 * D; i += 256) acc[i] = 0.f;
-    __syncthreads();
+    float* mine = acc + (size_t)wave * 2 * D;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lg + c * G;
-      if (ch < nchunk) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          atomicAdd(&acc[ch * 8 + i], dg[c][i]);
-          atomicAdd(&acc[D + ch * 8 + i], db[c][i]);
+      for (int i = 0; i < 8; ++i) {
+        float a = dg[c][i], b = db[c][i];
+        if (G == 32) {
+          ln_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+          a = __uint_as_float(r.x) + __uint_as_float(r.y);
+          r = __builtin_amdgcn_permlane32_swap(__float_as_uint(b), __float_as_uint(b), false, false);
+          b = __uint_as_float(r.x) + __uint_as_float(r.y);
         }
+        if (ch < nchunk && sub == 0) { mine[ch * 8 + i] = a; mine[D + ch * 8 + i] = b; }
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += 256) {
-      atomicAdd(&dgamma[i], acc[i]);
-      atomicAdd(&dbeta[i], acc[D + i]);
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+      const float v = (acc[i] + acc[2 * D + i]) + (acc[4 * D + i] + acc[6 * D + i]);
+      atomicAdd(i < D ? &dgamma[i] : &dbeta[i - D], v);
     }
   }
 }
@@ -266,10 +271,13 @@ extern "C" int basd_layernorm_bwd_bf16(const void* dy, const void* x, const floa
   if (rows <= 0) return BASD_OK;
   if (D % 8 || D < 8 || D > 2048) return fail(BASD_ERR_SHAPE, "layernorm_bwd_bf16: D %% 8 != 0 or D > 2048 (%d)", D);
   const int nchunk = D / 8;
-  const size_t lds = (size_t)2 * D * 4;
+  const size_t lds = (size_t)4 * 2 * D * 4;
   hipStream_t st = (hipStream_t)stream;
+  // every workgroup ends with one fp32 atomic per column into the same 2 D addresses, which the memory side
+  // serialises (~20 ns per workgroup, measured): 512 workgroups balance that tail against load parallelism
+  const int bwd_cap = 512;
 #define BASD_LN_BWD(G, NCH)                                                                                       \
-  hipLaunchKernelGGL((ln_bwd_kernel<G, NCH>), dim3(ln_grid(rows, 4 * (64 / G) * 4, 1024)), dim3(256), lds, st,      \
+  hipLaunchKernelGGL((ln_bwd_kernel<G, NCH>), dim3(ln_grid(rows, 4 * (64 / G) * 4, bwd_cap)), dim3(256), lds, st,   \
                      (const unsigned short*)dy, (const unsigned short*)x, gamma, mean, rstd, rows, D,               \
                      (unsigned short*)dx, dgamma, dbeta)
   if (nchunk <= 32) BASD_LN_BWD(32, 1);

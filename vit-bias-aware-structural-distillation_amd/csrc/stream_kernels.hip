@@ -141,13 +141,156 @@ __global__ __launch_bounds__(256) void mix_grad_dots_kernel(LayerPtrs layers, in
   for (int i = threadIdx.x; i < E * L; i += blockDim.x) atomicAdd(&dots[i], s_acc[i]);
 }
 
-// Procrustes backward, row epilogue: R = W - (other side) G^T was formed by the GEMM (beta = 1);
-// here  out[row, :] = 2 gl sqrt(a[row]) R[row, :]   (the gradient w.r.t. the raw tokens) and
-// rowdot[row] = 2 gl sum_d R[row, d] W[row, d]        (the part of d loss / d a this side owns)
-// in ONE pass over R and W (torch needed five elementwise passes over the [E*B, N, D_t] tensors).
-// One wave per row; out may alias r (fp32) or be a bf16 buffer.
+// Vectorised version for D_s, D_t multiples of 4 (default): one workgroup of 1024 threads per
+// sample = 4 token groups x 256 column quads; every thread streams 16-byte quads of its columns
+// for every 4th token (the kernel above walks one column per thread, a dependent scalar load per
+// token: 1.3 TB/s).  Same arithmetic per element; the weighted means are combined over the four
+// token groups through LDS.
+template <typename TS>
+__device__ __forceinline__ float4 load_quad(const TS* p) {
+  if constexpr (sizeof(TS) == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                       __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+
+template <typename TS>
+__global__ __launch_bounds__(1024) void procrustes_prep_v4_kernel(
+    const TS* __restrict__ s_all, const float* __restrict__ t_all, const float* __restrict__ imp_all,
+    int N_s, int N_t, int D_s, int D_t, int64_t s_batch_stride, float* __restrict__ sw_all,
+    float* __restrict__ tw_all, float* __restrict__ a_all, float* __restrict__ tr_all) {
+  extern __shared__ __align__(16) float sm[];
+  const int D = D_s + D_t;
+  float* s_a = sm;                                   // [N_s] normalised importance
+  float* s_ra = s_a + N_s;                           // [N_s] its square root
+  int* s_lo = reinterpret_cast<int*>(s_ra + N_s);    // [N_s]
+  float* s_fr = reinterpret_cast<float*>(s_lo + N_s);  // [N_s]
+  float* s_part = s_fr + N_s + ((4 - (4 * N_s) % 4) % 4);   // [4][D] partial weighted sums (16-byte aligned: N_s*4 floats)
+  float* s_mu = s_part + 4 * D;                      // [D]
+  float* s_red = s_mu + D;                           // [64]
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const TS* s = s_all + (size_t)b * s_batch_stride;
+  const float* t = t_all + (size_t)b * N_t * D_t;
+  const float* imp = imp_all + (size_t)b * N_t;
+  float* sw = sw_all + (size_t)b * N_s * D_s;
+  float* tw = tw_all + (size_t)b * N_s * D_t;
+  const bool same_n = (N_t == N_s);
+
+  const float ratio = (float)N_t / (float)N_s;
+  float part = 0.f;
+  for (int n = tid; n < N_s; n += nt) {
+    float pos = ((float)n + 0.5f) * ratio - 0.5f;
+    pos = pos < 0.f ? 0.f : pos;
+    int lo = (int)pos;
+    if (lo > N_t - 1) lo = N_t - 1;
+    const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+    const float fr = same_n ? 0.f : pos - (float)lo;
+    const float v = same_n ? imp[n] : imp[lo] * (1.f - fr) + imp[hi] * fr;
+    s_a[n] = v; s_lo[n] = lo; s_fr[n] = fr;
+    part += v;
+  }
+  part = wave_sum(part);
+  if ((tid & 63) == 0) s_red[tid >> 6] = part;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < (nt >> 6); ++w) tot += s_red[w];
+  __syncthreads();
+  for (int n = tid; n < N_s; n += nt) {
+    const float an = s_a[n] / tot;
+    s_a[n] = an;
+    s_ra[n] = sqrtf(an);
+    a_all[(size_t)b * N_s + n] = an;
+  }
+  __syncthreads();
+  const int tg = tid >> 8, cq = tid & 255;
+  const int Q = D >> 2, Qs = D_s >> 2;
+  // ---- weighted column sums, four token groups
+  for (int q = cq; q < Q; q += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Qs) {
+      for (int n = tg; n < N_s; n += 4) {
+        const float4 x = load_quad<TS>(s + (size_t)n * D_s + 4 * q);
+        const float an = s_a[n];
+        acc.x = fmaf(an, x.x, acc.x); acc.y = fmaf(an, x.y, acc.y); acc.z = fmaf(an, x.z, acc.z); acc.w = fmaf(an, x.w, acc.w);
+      }
+    } else {
+      const int dd = 4 * (q - Qs);
+      for (int n = tg; n < N_s; n += 4) {
+        const int lo = s_lo[n];
+        float4 x = *reinterpret_cast<const float4*>(t + (size_t)lo * D_t + dd);
+        const float fr = s_fr[n];
+        if (fr != 0.f) {
+          const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+          const float4 y = *reinterpret_cast<const float4*>(t + (size_t)hi * D_t + dd);
+          x.x = x.x * (1.f - fr) + y.x * fr; x.y = x.y * (1.f - fr) + y.y * fr;
+          x.z = x.z * (1.f - fr) + y.z * fr; x.w = x.w * (1.f - fr) + y.w * fr;
+        }
+        const float an = s_a[n];
+        acc.x = fmaf(an, x.x, acc.x); acc.y = fmaf(an, x.y, acc.y); acc.z = fmaf(an, x.z, acc.z); acc.w = fmaf(an, x.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(s_part + (size_t)tg * D + 4 * q) = acc;
+  }
+  __syncthreads();
+  for (int d = tid; d < D; d += nt) s_mu[d] = (s_part[d] + s_part[D + d]) + (s_part[2 * D + d] + s_part[3 * D + d]);
+  __syncthreads();
+  // ---- centre, weight, write; traces
+  double trs = 0.0, trt = 0.0;
+  for (int q = cq; q < Q; q += 256) {
+    const float4 mu = *reinterpret_cast<const float4*>(s_mu + 4 * q);
+    if (q < Qs) {
+      float acc = 0.f;
+      for (int n = tg; n < N_s; n += 4) {
+        const float4 x = load_quad<TS>(s + (size_t)n * D_s + 4 * q);
+        const float ra = s_ra[n];
+        const float4 v = make_float4(ra * (x.x - mu.x), ra * (x.y - mu.y), ra * (x.z - mu.z), ra * (x.w - mu.w));
+        *reinterpret_cast<float4*>(sw + (size_t)n * D_s + 4 * q) = v;
+        acc = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, acc))));
+        if ((n & 31) == 31) { trs += (double)acc; acc = 0.f; }     // short fp32 runs, fp64 across them
+      }
+      trs += (double)acc;
+    } else {
+      const int dd = 4 * (q - Qs);
+      float acc = 0.f;
+      for (int n = tg; n < N_s; n += 4) {
+        const int lo = s_lo[n];
+        float4 x = *reinterpret_cast<const float4*>(t + (size_t)lo * D_t + dd);
+        const float fr = s_fr[n];
+        if (fr != 0.f) {
+          const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+          const float4 y = *reinterpret_cast<const float4*>(t + (size_t)hi * D_t + dd);
+          x.x = x.x * (1.f - fr) + y.x * fr; x.y = x.y * (1.f - fr) + y.y * fr;
+          x.z = x.z * (1.f - fr) + y.z * fr; x.w = x.w * (1.f - fr) + y.w * fr;
+        }
+        const float ra = s_ra[n];
+        const float4 v = make_float4(ra * (x.x - mu.x), ra * (x.y - mu.y), ra * (x.z - mu.z), ra * (x.w - mu.w));
+        *reinterpret_cast<float4*>(tw + (size_t)n * D_t + dd) = v;
+        acc = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, acc))));
+        if ((n & 31) == 31) { trt += (double)acc; acc = 0.f; }
+      }
+      trt += (double)acc;
+    }
+  }
+  trs = wave_sum_d(trs); trt = wave_sum_d(trt);
+  if ((tid & 63) == 0) { s_red[tid >> 6] = (float)trs; s_red[32 + (tid >> 6)] = (float)trt; }
+  __syncthreads();
+  if (tid == 0) {
+    float x = 0.f, y = 0.f;
+    for (int w = 0; w < (nt >> 6); ++w) { x += s_red[w]; y += s_red[32 + w]; }
+    tr_all[(size_t)b * 2] = x; tr_all[(size_t)b * 2 + 1] = y;
+  }
+}
+
+// Procrustes backward, row epilogue.  p = (other side) G^T comes from a plain GEMM; with R = W - p
+//   out[row, :] = 2 gl sqrt(a[row]) R[row, :]   (the gradient w.r.t. the raw tokens) and
+//   rowdot[row] = 2 gl sum_d R[row, d] W[row, d]  (the part of d loss / d a this side owns)
+// in ONE pass over p and W (torch needed five elementwise passes over the [E*B, N, D_t] tensors).
+// One wave per row; out may alias p (fp32) or be a bf16 buffer.
 template <typename TO>
-__global__ __launch_bounds__(256) void procrustes_bwd_rows_kernel(const float* __restrict__ r, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void procrustes_bwd_rows_kernel(const float* __restrict__ p, const float* __restrict__ w,
                                                                   const float* __restrict__ a, const float* __restrict__ gl,
                                                                   int64_t rows, int rows_per_batch, int D, TO* out,
                                                                   float* __restrict__ rowdot) {
@@ -156,11 +299,12 @@ __global__ __launch_bounds__(256) void procrustes_bwd_rows_kernel(const float* _
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const float c2 = 2.f * gl[row / rows_per_batch];
     const float c = c2 * sqrtf(a[row]);
-    const float4* r4 = reinterpret_cast<const float4*>(r + row * D);
+    const float4* p4 = reinterpret_cast<const float4*>(p + row * D);
     const float4* w4 = reinterpret_cast<const float4*>(w + row * D);
     float dot = 0.f;
     for (int q = lane; q < nq; q += 64) {
-      const float4 rv = r4[q], wv = w4[q];
+      const float4 pv = p4[q], wv = w4[q];
+      const float4 rv = make_float4(wv.x - pv.x, wv.y - pv.y, wv.z - pv.z, wv.w - pv.w);
       dot = fmaf(rv.x, wv.x, fmaf(rv.y, wv.y, fmaf(rv.z, wv.z, fmaf(rv.w, wv.w, dot))));
       if constexpr (sizeof(TO) == 4) {
         reinterpret_cast<float4*>(out + row * D)[q] = make_float4(c * rv.x, c * rv.y, c * rv.z, c * rv.w);
@@ -403,6 +547,18 @@ extern "C" int basd_procrustes_prep(const void* s, int s_dtype, int64_t s_batch_
   const size_t lds = (size_t)(3 * N_s + D_s + D_t + 32) * 4;
   if (lds > 160 * 1024) return fail(BASD_ERR_SHAPE, "procrustes_prep: LDS %zu too large", lds);
   hipStream_t st = (hipStream_t)stream;
+  const size_t lds4 = ((size_t)4 * N_s + 4 + 5 * (size_t)(D_s + D_t) + 64) * 4;
+  const bool vec_ok = D_s % 4 == 0 && D_t % 4 == 0 && s_batch_stride % 4 == 0 && ((uintptr_t)s & 15) == 0 &&
+                      ((uintptr_t)t & 15) == 0 && ((uintptr_t)s_w & 15) == 0 && ((uintptr_t)t_w & 15) == 0 && lds4 <= 64 * 1024;
+  if (vec_ok && (s_dtype == BASD_DTYPE_F32 || s_dtype == BASD_DTYPE_BF16)) {
+    if (s_dtype == BASD_DTYPE_F32)
+      hipLaunchKernelGGL(procrustes_prep_v4_kernel<float>, dim3(B), dim3(1024), lds4, st, (const float*)s, t, imp,
+                         N_s, N_t, D_s, D_t, s_batch_stride, s_w, t_w, a, tr);
+    else
+      hipLaunchKernelGGL(procrustes_prep_v4_kernel<unsigned short>, dim3(B), dim3(1024), lds4, st,
+                         (const unsigned short*)s, t, imp, N_s, N_t, D_s, D_t, s_batch_stride, s_w, t_w, a, tr);
+    return check_launch("procrustes_prep (vectorised)");
+  }
   if (s_dtype == BASD_DTYPE_F32) {
     hipLaunchKernelGGL(procrustes_prep_kernel<float>, dim3(B), dim3(512), lds, st, (const float*)s, t, imp,
                        N_s, N_t, D_s, D_t, s_batch_stride, s_w, t_w, a, tr);

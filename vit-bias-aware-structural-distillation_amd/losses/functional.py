@@ -279,12 +279,10 @@ class _ProcrustesFn(torch.autograd.Function):
         n_s, n_t = s_w.shape[1], ctx.n_t
         ops = get_ops()
         gl = g_loss.float().reshape(-1).contiguous()
-        # R = W - (other side) G^T in the GEMM epilogue (beta = 1); scaling by 2 gl sqrt(a) and the row
-        # dots <R, W> that make up d loss / d a in one fused pass per side
-        r_s = torch.baddbmm(s_w, t_w, g.transpose(1, 2), beta=1.0, alpha=-1.0)
-        r_t = torch.baddbmm(t_w, s_w, g, beta=1.0, alpha=-1.0)
-        g_s, dot_s = ops.procrustes_bwd_rows(r_s, s_w, a, gl, out_dtype=ctx.s_dtype)
-        g_t, dot_t = ops.procrustes_bwd_rows(r_t, t_w, a, gl, out_dtype=torch.float32)
+        # residuals R = W - (other side) G^T, their scaling by 2 gl sqrt(a) and the row dots <R, W> that
+        # make up d loss / d a: one fused pass per side over the GEMM result
+        g_s, dot_s = ops.procrustes_bwd_rows(t_w @ g.transpose(1, 2), s_w, a, gl, out_dtype=ctx.s_dtype)
+        g_t, dot_t = ops.procrustes_bwd_rows(s_w @ g, t_w, a, gl, out_dtype=torch.float32)
         g_a = (dot_s + dot_t) / (2.0 * a)
         imp = imp_all.float().reshape(-1, n_t)
         if n_t != n_s:
