@@ -47,3 +47,29 @@ def test_eager_step_is_deterministic_up_to_atomics():
     la, _ = a.train_step(batch)
     lb, _ = b.train_step(batch)
     torch.testing.assert_close(la, lb, rtol=1e-5, atol=0)
+
+
+@pytest.mark.gpu
+def test_packed_attention_matches_plain_sdpa():
+    """the direct flash-attention call with a packed qkv gradient equals autograd through F.sdpa"""
+    import basd_amd.models.vit as V
+    torch.manual_seed(0)
+    attn = V.Attention(192, 3).cuda().to(torch.bfloat16)
+    x = torch.randn(8, 197, 192, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    g = torch.randn(8, 197, 192, device="cuda", dtype=torch.bfloat16)
+    assert V._packed_attention_ok
+    y1 = attn(x)
+    y1.backward(g)
+    assert V._packed_attention_ok, "the direct library call failed on this build"
+    gx1, gw1 = x.grad.clone(), attn.qkv.weight.grad.clone()
+    x.grad = None
+    attn.qkv.weight.grad = None
+    V._packed_attention_ok = False
+    try:
+        y2 = attn(x)
+        y2.backward(g)
+    finally:
+        V._packed_attention_ok = True
+    assert torch.equal(y1, y2)
+    assert torch.allclose(gx1.float(), x.grad.float(), rtol=2e-2, atol=2e-3)
+    assert torch.allclose(gw1.float(), attn.qkv.weight.grad.float(), rtol=2e-2, atol=2e-2)

@@ -116,6 +116,42 @@ class LayerScale(nn.Module):
         return x * self.gamma
 
 
+class _PackedFlashAttention(torch.autograd.Function):
+    """softmax(QK^T / sqrt(hd)) V on the packed projection [B, T, 3 * H * hd] with a packed gradient.
+
+    Through plain autograd the three gradients of the library's flash-attention backward are stacked
+    (unbind backward) and then copied once more into the [B, T, 3, H, hd] order the qkv Linear wants:
+    two extra passes over the projection gradient per block.  Here the same library kernels are called
+    directly (aten::_scaled_dot_product_flash_attention[_backward]) and their three outputs, which are
+    [B, T, H, hd]-contiguous, are interleaved once."""
+
+    @staticmethod
+    def forward(ctx, qkv_flat, heads, head_dim):
+        b, t, _ = qkv_flat.shape
+        qkv = qkv_flat.view(b, t, 3, heads, head_dim)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))              # [B, H, T, hd] views
+        res = torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, False, False)
+        out, lse, cum_q, cum_k, max_q, max_k, seed, offset = res[:8]
+        ctx.save_for_backward(qkv_flat, out, lse, cum_q, cum_k, seed, offset)
+        ctx.dims = (heads, head_dim, max_q, max_k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv_flat, out, lse, cum_q, cum_k, seed, offset = ctx.saved_tensors
+        heads, head_dim, max_q, max_k = ctx.dims
+        b, t, _ = qkv_flat.shape
+        qkv = qkv_flat.view(b, t, 3, heads, head_dim)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+        dq, dk, dv = torch.ops.aten._scaled_dot_product_flash_attention_backward(
+            g, q, k, v, out, lse, cum_q, cum_k, max_q, max_k, 0.0, False, seed, offset)
+        dqkv = torch.stack((dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)), dim=2)   # [B, T, 3, H, hd]
+        return dqkv.view(b, t, 3 * heads * head_dim), None, None
+
+
+_packed_attention_ok = True      # cleared on the first failure of the direct library call (other torch builds)
+
+
 class Attention(nn.Module):
     def __init__(self, dim: int, num_heads: int, qkv_bias: bool = True):
         super().__init__()
@@ -139,7 +175,16 @@ class Attention(nn.Module):
                 self.tap["out"] = ops.cls_importance(qkv_flat, self.num_heads, self.head_dim, self.scale)
             else:
                 self.tap["out"] = self._importance(q, k, self.tap["has_cls"])
-        out = F.scaled_dot_product_attention(q, k, v)
+        global _packed_attention_ok
+        out = None
+        if (_packed_attention_ok and qkv_flat.is_cuda and qkv_flat.dtype in (torch.bfloat16, torch.float16)
+                and torch.is_grad_enabled() and qkv_flat.requires_grad and qkv_flat.is_contiguous()):
+            try:
+                out = _PackedFlashAttention.apply(qkv_flat, self.num_heads, self.head_dim)
+            except (RuntimeError, AttributeError, TypeError):
+                _packed_attention_ok = False
+        if out is None:
+            out = F.scaled_dot_product_attention(q, k, v)
         return self.proj(out.transpose(1, 2).reshape(b, t, c))
 
     def _importance(self, q, k, has_cls: bool):
