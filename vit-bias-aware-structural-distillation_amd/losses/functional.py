@@ -110,7 +110,7 @@ def teacher_frames(teacher_tokens, proj_t):
 
 class _SelectorWeightsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_temp, proj_s, ranks, keep, vm_t, sw, *student):
+    def forward(ctx, log_temp, proj_s, ranks, keep, vm_t, sw, ready, *student):
         ops = get_ops()
         E, L = len(student), vm_t.shape[0]
         D = proj_s.shape[0]
@@ -123,6 +123,9 @@ class _SelectorWeightsFn(torch.autograd.Function):
             mats.append(g - torch.outer(c, c) / m_s)
         sigma_s, v_s, _ = psd_eig(torch.stack(mats))
         lam_s = sigma_s.double() ** 2
+        if ready is not None:
+            ready()           # join the stream that produced the teacher frames only now: the student's own
+                              # (latency-bound, 8-workgroup) eigen-solve above overlaps the teacher's
 
         a_full = torch.einsum("ibd,jcd->ijbc", v_s, vm_t)           # [E, L, D(b), D(c)]
         a_bar = a_full * keep.view(1, L, D, 1)                      # rows b < k_j
@@ -180,7 +183,7 @@ class _SelectorWeightsFn(torch.autograd.Function):
             # centring z = s P^T over rows == centring s (linear map), so d loss / d s = (s - mean) W
             centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
             grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
-        return (g_lt, None, None, None, None, None, *grads)
+        return (g_lt, None, None, None, None, None, None, *grads)
 
 
 def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_temperatures, frames=None):
@@ -191,7 +194,7 @@ def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_tempera
         frames = teacher_frames([t.detach() for t in teacher_tokens], proj_t)
     # batch-strided views (CLS-stripped block outputs) are consumed in place
     wts, pre = _SelectorWeightsFn.apply(log_temperatures, proj_s, frames["ranks"], frames["keep"], frames["vm_t"],
-                                        frames["sw"], *student_tokens)
+                                        frames["sw"], frames.get("ready"), *student_tokens)
     return wts, frames["ranks"], pre
 
 

@@ -78,14 +78,31 @@ class GrassmannianLayerSelector(nn.Module):
         of ``forward`` -- e.g. on a side stream while the student forward runs.  Consumed by the next
         ``mixing_weights`` / ``forward`` call."""
         teacher_indices = sorted(all_teacher_tokens.keys())
-        self._frames = (teacher_indices,
-                        BF.teacher_frames([all_teacher_tokens[j].detach() for j in teacher_indices], self.proj_t))
+        frames = BF.teacher_frames([all_teacher_tokens[j].detach() for j in teacher_indices], self.proj_t)
+        if self.proj_t.is_cuda:
+            # produced on the caller's current (possibly side) stream: the consumer joins it through this
+            # event at the point of use, after its own student statistics have been enqueued
+            done = torch.cuda.Event()
+            done.record()
+            tensors = [t for t in frames.values() if isinstance(t, torch.Tensor)]
+
+            def ready():
+                cur = torch.cuda.current_stream()
+                cur.wait_event(done)
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in tensors:
+                        t.record_stream(cur)
+            frames["ready"] = ready
+        self._frames = (teacher_indices, frames)
 
     def mixing_weights(self, student_tokens_per_layer, all_teacher_tokens, extraction_indices):
         teacher_indices = sorted(all_teacher_tokens.keys())
         frames = None
-        if self._frames is not None and self._frames[0] == teacher_indices:
-            frames = self._frames[1]
+        if self._frames is not None:
+            if self._frames[0] == teacher_indices:
+                frames = self._frames[1]
+            elif "ready" in self._frames[1]:
+                self._frames[1]["ready"]()           # unused precomputation: still join its stream
         self._frames = None
         weights, ranks, pre = BF.selector_weights(
             [student_tokens_per_layer[l] for l in extraction_indices],

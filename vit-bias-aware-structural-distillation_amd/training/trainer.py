@@ -107,13 +107,12 @@ class Trainer:
             logits, s_tokens = _extract_student(
                 self.model, student_imgs, self.basd_loss.token_layers,
                 layer_paths=self._student_layer_paths, has_cls_token=self._student_has_cls)
-        if side is not None:
-            main.wait_stream(side)
-            frames = self.basd_loss.layer_selector._frames
-            if frames is not None and not capturing:
-                for t in frames[1].values():
-                    t.record_stream(main)
+        # no join here: the selector waits for the side stream (event recorded by precompute_teacher) only
+        # where it consumes the teacher frames, so the student's statistics overlap the teacher's
         loss = self.basd_loss(logits.float(), mixed_targets, s_tokens, t_tokens, t_importance)
+        if side is not None and self.basd_loss.layer_selector._frames is not None:
+            main.wait_stream(side)               # the loss did not consume the precomputation: join anyway
+            self.basd_loss.layer_selector._frames = None
         loss.backward()
         return loss.detach(), logits.detach()
 
