@@ -230,7 +230,7 @@ def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
     Q2 = L^-1 cross with orthonormal rows) is diagonalised by the fp32 Jacobi:
     L J1 = U Sigma.  The right factor J1 = L^-1 (U Sigma) uses the explicit fp64 inverse of the graded L
     (never from a division by sigma), so (U, J1) is a consistent pair and
-    G = U J1^T Q2 is orthonormal to working precision.
+    G = U J1^T Q2 = (U J1^T L^-1) cross is orthonormal to working precision.
     """
     ops = get_ops()
     d_s = s_w.shape[-1]
@@ -245,9 +245,11 @@ def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
     j1 = ops.bgemm_f64(l_inv, wf, trans_b=True)                         # [B, k, i]:  L J1 = U Sigma
     u = torch.where(sigma.unsqueeze(-1) > 0, wf / sigma.clamp_min(1e-30).unsqueeze(-1),
                     torch.zeros(1, device=s_w.device))                  # [B, i, r]
-    theta = ops.bgemm_f64(u, j1, trans_a=True, trans_b=True, out_dtype=torch.float32)   # [B, r, k] = polar(L)
-    q2 = ops.bgemm_f64(l_inv, cross, out_dtype=torch.float32)           # [B, k, D_t], orthonormal rows
-    g = theta @ q2                                              # [B, D_s, D_t]
+    theta = ops.bgemm_f64(u, j1, trans_a=True, trans_b=True)            # [B, r, k] = polar(L), fp64
+    # G = theta Q2 with Q2 = L^-1 cross (orthonormal rows): associate as (theta L^-1) cross so that the
+    # [k, D_t] factor is never rounded to fp32 and the fp32 library bmm disappears (all on the fp64 MFMA)
+    m = ops.bgemm_f64(theta, l_inv)                                     # [B, r, r'] fp64
+    g = ops.bgemm_f64(m, cross, out_dtype=torch.float32)                # [B, D_s, D_t]
     return sigma.sum(dim=-1), g
 
 
