@@ -81,7 +81,7 @@ int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_b
  *   lwork[batch, n, n] fp64: the same columns in fp64 (column-major by step);
  *   piv  [batch, n] int32: pivot row chosen at step k (a permutation of 0..n-1);
  *   rank [batch] int32: number of pivots > tol * max diag.
- * n <= 256. */
+ * Only the LOWER triangle of a[b] (row >= column) is read.  n <= 256. */
 int basd_pchol_f64(const double* a, int batch, int n, double tol,
                    float* w0, int ld, double* lwork, int32_t* piv, int32_t* rank,
                    void* stream);

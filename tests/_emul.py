@@ -22,14 +22,18 @@ def jacobi_fits(n_cols: int, m_rows: int) -> bool:
     return n_cols <= 256 and n_cols * jacobi_ld(m_rows) * 4 + 520 * 4 <= JACOBI_LDS_BYTES
 
 
-def token_gram(x, proj):
+def token_gram(x, proj, mirror=True):
     x = x.reshape(-1, x.shape[-1])
     z = (x.float() @ proj.float().t()).double()
-    return z.t() @ z, z.sum(0)
+    g = z.t() @ z
+    if not mirror:                                   # like the kernels: the strict upper triangle is not meaningful
+        g = torch.tril(g) + torch.triu(torch.full_like(g, float("nan")), 1)
+    return g, z.sum(0)
 
 
 def pchol(a, tol=1e-13):
     a = a.double()
+    a = torch.tril(a) + torch.tril(a, -1).transpose(-1, -2)     # only the lower triangle is read
     batch, n, _ = a.shape
     ld = jacobi_ld(n)
     lwork = torch.zeros(batch, n, n, dtype=torch.float64)

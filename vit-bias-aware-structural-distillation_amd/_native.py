@@ -135,9 +135,10 @@ def _mirror_lower(gram: torch.Tensor) -> torch.Tensor:
     return low + torch.tril(gram, -1).t()
 
 
-def token_gram(x: torch.Tensor, proj: torch.Tensor):
+def token_gram(x: torch.Tensor, proj: torch.Tensor, mirror: bool = True):
     """x [M, d_in] or [B, N, d_in] view (f32/bf16), proj [d_out, d_in] f32 ->
-    gram [d_out, d_out] f64, colsum [d_out] f64."""
+    gram [d_out, d_out] f64, colsum [d_out] f64.  ``mirror=False`` leaves the strict upper triangle
+    unspecified (the kernels fill lower tiles only; ``pchol`` reads nothing else)."""
     _need_cuda(x, proj)
     x, m, d_in, rpb, bstride = _token_view(x)
     proj = proj.contiguous().float()
@@ -149,10 +150,10 @@ def token_gram(x: torch.Tensor, proj: torch.Tensor):
         ps = split_bf16x3(proj)
         _check(lib().basd_token_gram_bf16x3(_ptr(x), i64(m), d_in, rpb, i64(bstride), _ptr(ps), d_out, _ptr(gram),
                                             _ptr(colsum), _stream()), "basd_token_gram_bf16x3")
-        return _mirror_lower(gram), colsum
+        return (_mirror_lower(gram) if mirror else gram), colsum
     _check(lib().basd_token_gram(_ptr(x), _dtype_code(x), i64(m), d_in, rpb, i64(bstride), _ptr(proj), d_out,
                                  _ptr(gram), _ptr(colsum), _stream()), "basd_token_gram")
-    return _mirror_lower(gram), colsum
+    return (_mirror_lower(gram) if mirror else gram), colsum
 
 
 def pchol(a: torch.Tensor, tol: float = 1e-13):

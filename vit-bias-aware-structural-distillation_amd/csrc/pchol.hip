@@ -205,7 +205,9 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int j = 6 * tc + c;
-      R[r][c] = (i < n && j < n) ? A[(size_t)i * n + j] : 0.0;
+      // only the lower triangle of A is read (row >= column): producers that accumulate lower tiles only
+      // (basd_token_gram) need no mirroring pass
+      R[r][c] = (i < n && j < n) ? (i >= j ? A[(size_t)i * n + j] : A[(size_t)j * n + i]) : 0.0;
     }
   }
   unsigned cdone = 0;                               // bit c: column 6 tc + c was pivoted (or is padding)
@@ -386,7 +388,8 @@ __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ 
     double col = 0.0;
     if (part == 0 && r < n) {
       if (s_alive[r]) {
-        const double v = A[(size_t)pv * n + r] - (s_part[0][r] + s_part[1][r] + s_part[2][r] + s_part[3][r]);
+        const double apr = (pv >= r) ? A[(size_t)pv * n + r] : A[(size_t)r * n + pv];     // lower triangle only
+        const double v = apr - (s_part[0][r] + s_part[1][r] + s_part[2][r] + s_part[3][r]);
         s_part[0][r] = v;
       }
     }

@@ -37,8 +37,9 @@ class BasdShapeError(NotImplementedError):
 # --------------------------------------------------------------------------- #
 # helpers
 # --------------------------------------------------------------------------- #
-def psd_eig(a64: torch.Tensor):
-    """Batched eigen-decomposition of symmetric PSD fp64 matrices [b, n, n].
+def psd_eig(a64: torch.Tensor, lower_only: bool = False):
+    """Batched eigen-decomposition of symmetric PSD fp64 matrices [b, n, n]
+    (``lower_only``: only the lower triangles are meaningful, e.g. ``token_gram(..., mirror=False)``).
 
     Returns (sigma [b, n] fp32 descending = sqrt(eigenvalues), u [b, n, n] fp32 with
     ROW i the unit eigenvector i (zero rows beyond the numerical rank), aux).
@@ -49,8 +50,9 @@ def psd_eig(a64: torch.Tensor):
         raise BasdShapeError(
             f"{n}x{n} eigenproblem does not fit the 160 KiB LDS-resident Jacobi (n <= ~200); "
             "student widths above 192 are out of scope this round (DESIGN.md)")
-    a64 = 0.5 * (a64 + a64.transpose(-1, -2))
-    w0, lwork, piv, rank = ops.pchol(a64, PCHOL_TOL)
+    if not lower_only:
+        a64 = 0.5 * (a64 + a64.transpose(-1, -2))
+    w0, lwork, piv, rank = ops.pchol(a64, PCHOL_TOL)             # reads the lower triangle only
     sigma, _ = ops.jacobi_svd(w0, n)
     safe = sigma.clamp_min(1e-30).unsqueeze(-1)
     u = torch.where(sigma.unsqueeze(-1) > 0, w0[:, :, :n] / safe, torch.zeros_like(w0[:, :, :n]))
@@ -97,10 +99,10 @@ def teacher_frames(teacher_tokens, proj_t):
     m_t = teacher_tokens[0].shape[0] * teacher_tokens[0].shape[1]
     unc, cen = [], []
     for x in teacher_tokens:                            # layer_selector.py:71-73, :134-136
-        g, c = ops.token_gram(x, proj_t)                # [B, N, D] view, no copy
+        g, c = ops.token_gram(x, proj_t, mirror=False)  # [B, N, D] view, no copy; lower triangle
         unc.append(g)
         cen.append(g - torch.outer(c, c) / m_t)
-    sigma, u, _ = psd_eig(torch.stack(unc + cen))
+    sigma, u, _ = psd_eig(torch.stack(unc + cen), lower_only=True)
     ranks = ops.mp_rank(sigma[:L] ** 2, m_t, D, D - 1)  # int32 [L], stays on device
     v_t, s_t = u[L:], sigma[L:]
     idx = torch.arange(D, device=proj_t.device)
@@ -119,9 +121,9 @@ class _SelectorWeightsFn(torch.autograd.Function):
         mats = []
         m_s = student[0].shape[0] * student[0].shape[1]
         for s in student:                               # layer_selector.py:84-92
-            g, c = ops.token_gram(s, proj_s)
+            g, c = ops.token_gram(s, proj_s, mirror=False)
             mats.append(g - torch.outer(c, c) / m_s)
-        sigma_s, v_s, _ = psd_eig(torch.stack(mats))
+        sigma_s, v_s, _ = psd_eig(torch.stack(mats), lower_only=True)
         lam_s = sigma_s.double() ** 2
         if ready is not None:
             ready()           # join the stream that produced the teacher frames only now: the student's own

@@ -46,11 +46,12 @@ class DropPath(nn.Module):
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
         return mask / keep
 
-    def add_to(self, residual, x):
-        """residual + drop_path(x) in one elementwise kernel (addcmul) instead of mul, div and add"""
+    def add_to(self, residual, x, mask=None):
+        """residual + drop_path(x) in one elementwise kernel (addcmul) instead of mul, div and add;
+        ``mask``: a pre-drawn scaled keep mask (the model draws all of a forward's masks in one launch)"""
         if self.p == 0.0 or not self.training:
             return residual + x
-        return torch.addcmul(residual, x, self.scaled_mask(x))
+        return torch.addcmul(residual, x, self.scaled_mask(x) if mask is None else mask)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -231,7 +232,7 @@ class Block(nn.Module):
                 and (not self.training or (self.drop_path1.p == 0.0 and self.drop_path2.p == 0.0))
                 and self.norm2.elementwise_affine and get_ops().layernorm_supported(x.shape[-1]))
 
-    def forward(self, x):
+    def forward(self, x, dp_masks=None):
         if self._fused_inference(x):
             a = self.attn(self.norm1(x))
             x, z = self.norm2.fused_add(x, a)
@@ -242,8 +243,9 @@ class Block(nn.Module):
             out, zn = nxt.fused_add(x, m)
             out._basd_prenorm = (nxt, zn)
             return out
-        x = self.drop_path1.add_to(x, self.ls1(self.attn(self.norm1(x))))
-        return self.drop_path2.add_to(x, self.ls2(self.mlp(self.norm2(x))))
+        m1, m2 = dp_masks if dp_masks is not None else (None, None)
+        x = self.drop_path1.add_to(x, self.ls1(self.attn(self.norm1(x))), m1)
+        return self.drop_path2.add_to(x, self.ls2(self.mlp(self.norm2(x))), m2)
 
 
 class PatchEmbed(nn.Module):
@@ -292,12 +294,29 @@ class VisionTransformer(nn.Module):
         if self.cls_token is not None:
             x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x], dim=1)
         x = x + self.pos_embed.to(x.dtype)
-        for blk in self.blocks:
+        masks = self._draw_drop_path_masks(x)
+        for i, blk in enumerate(self.blocks):
+            dp = None if masks is None else (masks[2 * i], masks[2 * i + 1])
             if self.grad_checkpointing and self.training and torch.is_grad_enabled():
-                x = checkpoint(blk, x, use_reentrant=False)
+                x = checkpoint(blk, x, dp, use_reentrant=False)
             else:
-                x = blk(x)
+                x = blk(x, dp)
         return self.norm(x)
+
+    def _draw_drop_path_masks(self, x):
+        """All 2 * depth stochastic-depth masks of one forward from ONE bernoulli launch (timm draws one per
+        DropPath call: 3 tiny kernels x 24); [2 * depth, B, 1, 1], already divided by the keep probability."""
+        if not self.training:
+            return None
+        ps = [p for blk in self.blocks for p in (blk.drop_path1.p, blk.drop_path2.p)]
+        if not any(p > 0.0 for p in ps):
+            return None
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep.device != x.device or keep.shape[0] != len(ps):
+            keep = torch.tensor([1.0 - p for p in ps], device=x.device, dtype=torch.float32).view(-1, 1)
+            self._dp_keep = keep
+        m = torch.bernoulli(keep.expand(-1, x.shape[0])) / keep
+        return m.to(x.dtype).view(len(ps), x.shape[0], 1, 1)
 
     def forward(self, x):
         x = self.forward_features(x)
