@@ -11,6 +11,8 @@ for signature compatibility and may be None: mixed precision is
 """
 from __future__ import annotations
 
+import os
+
 from collections import defaultdict
 from pathlib import Path
 
@@ -78,6 +80,7 @@ class Trainer:
         self.use_mixup = True
         self.autocast_dtype = torch.bfloat16
         self.overlap_teacher_stats = True
+        self.overlap_teacher_forward = os.environ.get("BASD_OVERLAP_TEACHER", "1") == "1"
         self._side = None
         self._graph = None
         self.graph_error = None
@@ -93,16 +96,26 @@ class Trainer:
     def _forward_backward(self, clean, student_imgs, mixed_targets):
         """teacher fwd -> (side stream) teacher statistics || student fwd -> loss -> backward."""
         self.flat.refresh_bf16()          # one cast kernel for every Linear weight of the student
-        # frozen teacher first: its selector statistics (12 Gram passes + 24 small eigenproblems that
-        # occupy 24 of the 256 CUs) then run on a side stream underneath the student forward
-        t_tokens, t_importance = extract_intermediates(self._teacher, clean)
+        # The frozen teacher and its selector statistics (12 Gram passes + 24 small eigenproblems that
+        # occupy 24 of the 256 CUs) are independent of the student forward.  overlap_teacher_forward:
+        # the whole teacher branch runs on the side stream next to the student forward (the teacher's
+        # MFMA-bound GEMMs and the student's small, memory-bound kernels fill each other's gaps);
+        # otherwise only the statistics do.
         side = self._side_stream()
         capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        if side is not None:
+        if side is not None and self.overlap_teacher_forward:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                t_tokens, t_importance = extract_intermediates(self._teacher, clean)
                 self.basd_loss.layer_selector.precompute_teacher(t_tokens)
+        else:
+            t_tokens, t_importance = extract_intermediates(self._teacher, clean)
+            if side is not None:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.basd_loss.layer_selector.precompute_teacher(t_tokens)
         with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
             logits, s_tokens = _extract_student(
                 self.model, student_imgs, self.basd_loss.token_layers,
@@ -113,6 +126,11 @@ class Trainer:
         if side is not None and self.basd_loss.layer_selector._frames is not None:
             main.wait_stream(side)               # the loss did not consume the precomputation: join anyway
             self.basd_loss.layer_selector._frames = None
+        if side is not None and self.overlap_teacher_forward and not capturing:
+            # eager mode: the teacher outputs were allocated on the side stream and are read on this one
+            for t in list(t_tokens.values()) + list(t_importance.values()):
+                if t is not None:
+                    t.record_stream(main)
         loss.backward()
         return loss.detach(), logits.detach()
 
