@@ -189,6 +189,14 @@ int basd_procrustes_bwd_rows(const float* p, const float* w, const float* a, con
 int basd_cls_importance_bf16(const void* qkv, int B, int T, int H, int hd, float scale, float* out,
                              void* stream);
 
+/* Fused attention forward of a frozen block (inference): qkv [B, T, 3, H, hd] bf16 (packed projection) ->
+ * out [B, T, H * hd] bf16 = softmax(Q K^T * scale) V per head (fp32 logits / probabilities, P rounded to bf16
+ * for the second product, like the library flash kernel it replaces on the teacher: torch SDPA called at
+ * timm Attention.forward).  importance (nullable): [B, H, T-1] fp32; receives per head the CLS-row softmax of
+ * basd_cls_importance_bf16 divided by H (the tap is the sum over the H axis).  hd == 64, T <= 272. */
+int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int hd, float scale, void* out,
+                            float* importance, void* stream);
+
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:
  *   v = b2 v + (1-b2) g^2 ; gn = g / (sqrt(v / bias_correction2) + eps) + wd * y

@@ -216,6 +216,20 @@ def add_layernorm_fwd(x, residual, gamma, beta, eps):
     return s, y
 
 
+def attention_fwd_supported(t, hd):
+    return hd == 64 and 1 <= t <= 272
+
+
+def attention_fwd(qkv, heads, head_dim, scale, want_importance=False):
+    b, t, _ = qkv.shape
+    x = qkv.reshape(b, t, 3, heads, head_dim).permute(2, 0, 3, 1, 4).float()
+    q, k, v = x[0], x[1], x[2]
+    p = ((q @ k.transpose(-1, -2)) * scale).softmax(dim=-1)
+    out = (p.to(torch.bfloat16).float() @ v).transpose(1, 2).reshape(b, t, heads * head_dim).to(torch.bfloat16)
+    imp = cls_importance(qkv, heads, head_dim, scale) if want_importance else None
+    return out, imp
+
+
 def layernorm_supported(d):
     return d % 8 == 0 and 8 <= d <= 2048
 

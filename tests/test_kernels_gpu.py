@@ -393,3 +393,26 @@ def test_procrustes_bwd_rows(nat, B, N, D, dt):
     assert out.dtype == dt
     assert torch.allclose(out.cpu().double(), want, rtol=tol, atol=tol * float(want.abs().max()))
     assert torch.allclose(dot.cpu().double(), want_dot, rtol=1e-5, atol=1e-5 * float(want_dot.abs().max()))
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 197, 12), (2, 50, 3), (2, 257, 2), (1, 1, 1), (2, 208, 1)])
+def test_attention_fwd_matches_sdpa(nat, B, T, H):
+    """fused teacher attention (+ tap) vs softmax(QK^T/sqrt(hd)) V in fp64 on the same bf16 inputs"""
+    hd = 64
+    g = torch.Generator().manual_seed(T * 7 + H)
+    qkv = (torch.randn(B, T, 3 * H * hd, generator=g) * 1.2).to(torch.bfloat16)
+    scale = hd ** -0.5
+    out, imp = nat.attention_fwd(qkv.cuda(), H, hd, scale, want_importance=T >= 2)
+    x = qkv.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).double()
+    q, k, v = x[0], x[1], x[2]
+    p = ((q @ k.transpose(-1, -2)) * scale).softmax(dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B, T, H * hd)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert out.shape == (B, T, H * hd) and out.dtype == torch.bfloat16
+    assert err < 2e-2 * float(ref.abs().max()) + 1e-3, err          # bf16 P and bf16 output rounding
+    if T >= 2:
+        logits = (q[:, :, :1] @ k.transpose(-2, -1)).float()
+        want = (logits.to(torch.bfloat16).float() * scale).softmax(dim=-1)[:, :, 0, 1:].mean(dim=1)
+        assert torch.allclose(imp.cpu(), want, rtol=2e-2, atol=1e-6)
+        if T <= 256:
+            assert torch.allclose(imp, nat.cls_importance(qkv.cuda(), H, hd, scale), rtol=2e-2, atol=1e-6)

@@ -22,7 +22,7 @@ EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
-    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows",
+    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16",
 )
 
 
@@ -389,6 +389,24 @@ def cls_importance(qkv: torch.Tensor, heads: int, head_dim: int, scale: float) -
     _check(lib().basd_cls_importance_bf16(_ptr(qkv), b, t, heads, head_dim, ctypes.c_float(scale), _ptr(out), _stream()),
            "basd_cls_importance_bf16")
     return out
+
+
+def attention_fwd_supported(t: int, hd: int) -> bool:
+    return hd == 64 and 1 <= t <= 272
+
+
+def attention_fwd(qkv: torch.Tensor, heads: int, head_dim: int, scale: float, want_importance: bool = False):
+    """qkv [B, T, 3 * heads * head_dim] bf16 -> (out [B, T, heads * head_dim] bf16, importance [B, T-1] fp32 | None).
+    Inference only (no autograd)."""
+    _need_cuda(qkv)
+    assert qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 3 * heads * head_dim
+    qkv = qkv.contiguous()
+    b, t = qkv.shape[0], qkv.shape[1]
+    out = torch.empty(b, t, heads * head_dim, dtype=torch.bfloat16, device=qkv.device)
+    imp = torch.empty(b, heads, t - 1, dtype=torch.float32, device=qkv.device) if want_importance else None
+    _check(lib().basd_attention_fwd_bf16(_ptr(qkv), b, t, heads, head_dim, ctypes.c_float(scale), _ptr(out), _ptr(imp),
+                                         _stream()), "basd_attention_fwd_bf16")
+    return out, (imp.sum(dim=1) if want_importance else None)
 
 
 def layernorm_supported(d: int) -> bool:

@@ -1,0 +1,259 @@
+// Fused attention forward for the frozen teacher blocks (inference): out = softmax(Q K^T / sqrt(hd)) V
+// straight from the packed qkv projection [B, T, 3, H, hd] (bf16) into [B, T, H * hd] (bf16) -- the
+// layout the output projection reads -- plus, optionally, the attention tap the distillation loss
+// consumes, per head: importance[b, h, t-1] = softmax_t(bf16(q_cls . k_t) * scale) / H  (summed over h by the
+// caller: atomics into a shared [B, T-1] row cost 45 us per call; reference
+// src/models/teacher.py:27-39 builds the full [B, H, T, T] map from a second qkv GEMM;
+// src/losses/relational.py:22-27 keeps the head-averaged CLS row).
+//
+// One workgroup (4 waves) per (batch, head).  T <= 272 tokens, hd = 64: K and V of the head live in LDS
+// (row-major, 144-byte rows), every wave owns 16-query tiles.
+//   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K rows from LDS (ds_read_b128), B = Q rows from global:
+//                 the accumulator of key tile kt holds, for query column lane & 15, the keys
+//                 16 kt + 4 (lane >> 4) + {0..3};
+//   softmax       per query over all its keys = over registers and over the four lane groups (xor 16, 32);
+//   O   = P V     A = P: the two S^T accumulators of a 32-key step ARE the A fragment (same query per lane,
+//                 eight keys; the contraction only needs A and B to agree on the key order), B = V through the
+//                 transposing LDS read ds_read_b64_tr_b16 on the same eight keys -- no transpose of P or V;
+//   the 16 x 64 output tile is staged through LDS so that every lane stores 16 contiguous bytes.
+// Arithmetic: fp32 logits and probabilities like a flash kernel (P rounded to bf16 for the second MFMA).
+#include "basd_common.h"
+
+namespace basd {
+
+typedef float at_f32x4 __attribute__((ext_vector_type(4)));
+typedef short at_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short at_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) at_v4s at_lds_v4s;
+
+constexpr int AT_HD = 64;
+constexpr int AT_LD = AT_HD + 8;          // LDS row stride in bf16 (144 B: 16-byte aligned, bank rotation)
+
+typedef float at_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 at_bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 (round to nearest even): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
+  at_bf16x2 r = __builtin_convertvector((at_f32x2){a, b}, at_bf16x2);
+  return *reinterpret_cast<unsigned int*>(&r);
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned int u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <int NKT>   // key tiles of 16: T <= 16 * NKT
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int T, int H,
+                                                            float scale, unsigned short* __restrict__ out,
+                                                            float* __restrict__ importance) {
+  constexpr int NKS = (NKT + 1) / 2;                 // 32-key steps of the P V product
+  constexpr int KROWS = 32 * NKS;                    // LDS rows (zero padded)
+  extern __shared__ __align__(16) unsigned short sm[];
+  unsigned short* Ks = sm;                           // [KROWS][AT_LD]
+  unsigned short* Vs = Ks + KROWS * AT_LD;           // [KROWS][AT_LD]
+  unsigned short* Os = Vs + KROWS * AT_LD;           // [4 waves][16][AT_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const size_t row = (size_t)3 * H * AT_HD;          // elements per token
+  const unsigned short* base = qkv + (size_t)b * T * row + (size_t)h * AT_HD;
+
+  // ---- stage K and V of this head (16-byte chunks; rows >= T are zero).  All loads are issued before the
+  //      first LDS store: a load-store-per-iteration loop exposes one HBM round trip per iteration (7 of
+  //      them: 14 us of a 24 us workgroup in the first version of this kernel).
+  constexpr int NLD = (KROWS * 8 + 255) / 256;
+  uint4 kreg[NLD], vreg[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx >> 3, c8 = idx & 7;
+    kreg[i] = make_uint4(0, 0, 0, 0);
+    vreg[i] = make_uint4(0, 0, 0, 0);
+    if (r < T) {
+      const unsigned short* p = base + (size_t)r * row + c8 * 8;
+      kreg[i] = *reinterpret_cast<const uint4*>(p + (size_t)H * AT_HD);
+      vreg[i] = *reinterpret_cast<const uint4*>(p + (size_t)2 * H * AT_HD);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx >> 3, c8 = idx & 7;
+    if (idx < KROWS * 8) {
+      *reinterpret_cast<uint4*>(Ks + r * AT_LD + c8 * 8) = kreg[i];
+      *reinterpret_cast<uint4*>(Vs + r * AT_LD + c8 * 8) = vreg[i];
+    }
+  }
+  __syncthreads();
+
+  const float sl2 = scale * 1.4426950408889634f;     // exp(x * scale) = exp2(x * sl2)
+  const int nqt = (T + 15) >> 4;
+  const int full_tiles = T >> 4;                     // key tiles without padding
+  unsigned short* Ow = Os + wave * 16 * AT_LD;
+  auto load_q = [&](int qt_, uint4 (&dst)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      dst[ks] = make_uint4(0, 0, 0, 0);
+      if (qt_ < nqt && qt_ * 16 + li < T)
+        dst[ks] = *reinterpret_cast<const uint4*>(base + (size_t)(qt_ * 16 + li) * row + 32 * ks + 8 * g);
+    }
+  };
+  uint4 qnext[2];
+  load_q(wave, qnext);
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q0 = qt * 16;
+    // Q fragments of this tile: query q0 + li, d = 32 ks + 8 g .. + 7 (fetched one tile ahead)
+    at_bf16x8 qf[2];
+    qf[0] = *reinterpret_cast<at_bf16x8*>(&qnext[0]);
+    qf[1] = *reinterpret_cast<at_bf16x8*>(&qnext[1]);
+    load_q(qt + 4, qnext);
+    // ---- S^T tiles
+    at_f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      at_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint4 kk = *reinterpret_cast<const uint4*>(Ks + (16 * kt + li) * AT_LD + 32 * ks + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const at_bf16x8*>(&kk), qf[ks], acc, 0, 0, 0);
+      }
+      s[kt] = acc;
+      if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most four tiles of K fragments in flight
+    }
+    // ---- the attention tap: CLS query (column 0 of tile 0) with bf16-rounded logits, head-averaged
+    if (importance != nullptr && qt == 0) {
+      float lr[NKT][4];                              // transient: dead before the P V product needs registers
+      float tmx = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const unsigned int w = pack_bf16(s[kt][r], s[kt][r + 1]);          // the autocast matmul's bf16 output
+          lr[kt][r] = __uint_as_float(w << 16) * scale;
+          lr[kt][r + 1] = __uint_as_float(w & 0xffff0000u) * scale;
+          if (kt >= full_tiles) {
+            if (16 * kt + 4 * g + r >= T) lr[kt][r] = -3.0e38f;
+            if (16 * kt + 4 * g + r + 1 >= T) lr[kt][r + 1] = -3.0e38f;
+          }
+          tmx = fmaxf(tmx, fmaxf(lr[kt][r], lr[kt][r + 1]));
+        }
+      tmx = fmaxf(tmx, __shfl_xor(tmx, 16, 64));
+      tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
+      float tsum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lr[kt][r] = __builtin_amdgcn_exp2f((lr[kt][r] - tmx) * 1.4426950408889634f);
+          tsum += lr[kt][r];
+        }
+      tsum += __shfl_xor(tsum, 16, 64);
+      tsum += __shfl_xor(tsum, 32, 64);
+      if (li == 0) {
+        const float tinv = 1.f / (tsum * (float)H);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * g + r;
+            if (key >= 1 && (kt < full_tiles || key < T))
+              importance[((size_t)b * H + h) * (T - 1) + key - 1] = lr[kt][r] * tinv;
+          }
+      }
+    }
+    // ---- softmax over the keys of every query column
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt >= full_tiles && 16 * kt + 4 * g + r >= T) s[kt][r] = -3.0e38f;   // only the last tiles can hold padding keys
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f((s[kt][r] - mx) * sl2);   // v_exp_f32; padding keys: exp2(-huge) = 0
+        s[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    // ---- O = P V
+    at_f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (at_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int K1 = (2 * ks + 1 < NKT) ? 2 * ks + 1 : 0;      // constant after unrolling
+      uint4 pw;
+      pw.x = pack_bf16(s[2 * ks][0] * inv, s[2 * ks][1] * inv);
+      pw.y = pack_bf16(s[2 * ks][2] * inv, s[2 * ks][3] * inv);
+      pw.z = (2 * ks + 1 < NKT) ? pack_bf16(s[K1][0] * inv, s[K1][1] * inv) : 0u;
+      pw.w = (2 * ks + 1 < NKT) ? pack_bf16(s[K1][2] * inv, s[K1][3] * inv) : 0u;
+      const at_bf16x8 pa = *reinterpret_cast<const at_bf16x8*>(&pw);
+      // B fragment: column d = 16 dt + li, keys {32 ks + 4 g + e} and {32 ks + 16 + 4 g + e}, e = 0..3
+      const int qq = li >> 2, pp = li & 3;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const unsigned short* a0 = Vs + (32 * ks + 4 * g + qq) * AT_LD + 16 * dt + 4 * pp;
+        const at_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s*)a0);
+        const at_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s*)(a0 + 16 * AT_LD));
+        const at_bf16x8 vb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dt], 0, 0, 0);
+      }
+    }
+    // ---- o[dt][r] = O[query q0 + 4 g + r][d = 16 dt + li]: through LDS, then 16-byte row stores
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const unsigned int w = pack_bf16(o[dt][r], o[dt][r + 1]);
+        Ow[(4 * g + r) * AT_LD + 16 * dt + li] = (unsigned short)(w & 0xffffu);
+        Ow[(4 * g + r + 1) * AT_LD + 16 * dt + li] = (unsigned short)(w >> 16);
+      }
+    // the tile is private to this wave: LDS operations of a wave complete in order
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int idx = lane + 64 * c, r = idx >> 3, c8 = idx & 7;
+      if (q0 + r < T) {
+        const uint4 v = *reinterpret_cast<const uint4*>(Ow + r * AT_LD + c8 * 8);
+        *reinterpret_cast<uint4*>(out + ((size_t)(b * T + q0 + r) * H + h) * AT_HD + c8 * 8) = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
+template <int NKT>
+static void launch_attention(const void* qkv, int B, int T, int H, float scale, void* out, float* importance,
+                             hipStream_t st) {
+  constexpr int KROWS = 32 * ((NKT + 1) / 2);
+  const size_t lds = ((size_t)2 * KROWS * AT_LD + 4 * 16 * AT_LD) * sizeof(unsigned short);
+  allow_full_lds((const void*)attention_fwd_kernel<NKT>);
+  hipLaunchKernelGGL(attention_fwd_kernel<NKT>, dim3(B * H), dim3(256), lds, st, (const unsigned short*)qkv, T, H, scale,
+                     (unsigned short*)out, importance);
+}
+
+}  // namespace basd
+
+extern "C" int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int hd, float scale, void* out,
+                                       float* importance, void* stream) {
+  using namespace basd;
+  if (B <= 0) return BASD_OK;
+  if (hd != AT_HD || T < 1 || T > 272 || H < 1)
+    return fail(BASD_ERR_SHAPE, "attention_fwd: T=%d H=%d hd=%d unsupported (hd 64, T <= 272)", T, H, hd);
+  if (importance != nullptr && T < 2) return fail(BASD_ERR_SHAPE, "attention_fwd: importance needs T >= 2");
+  hipStream_t st = (hipStream_t)stream;
+  if (T <= 64) launch_attention<4>(qkv, B, T, H, scale, out, importance, st);
+  else if (T <= 208) launch_attention<13>(qkv, B, T, H, scale, out, importance, st);
+  else launch_attention<17>(qkv, B, T, H, scale, out, importance, st);
+  return check_launch("attention_fwd");
+}

@@ -20,6 +20,7 @@ timm is absent) -- see DESIGN.md.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -150,6 +151,7 @@ class _PackedFlashAttention(torch.autograd.Function):
         return dqkv.view(b, t, 3 * heads * head_dim), None, None
 
 
+_FUSED_TEACHER_ATTENTION = os.environ.get("BASD_FUSED_ATTN", "1") == "1"     # 0: library SDPA + separate tap (A/B runs)
 _packed_attention_ok = True      # cleared on the first failure of the direct library call (other torch builds)
 
 
@@ -166,6 +168,19 @@ class Attention(nn.Module):
     def forward(self, x):
         b, t, c = x.shape
         qkv_flat = self.qkv(x)
+        if (_FUSED_TEACHER_ATTENTION and not torch.is_grad_enabled() and qkv_flat.dtype == torch.bfloat16
+                and (qkv_flat.is_cuda or is_emulated()) and get_ops().attention_fwd_supported(t, self.head_dim)):
+            # frozen block: fused attention straight from the packed projection, the tap as a by-product
+            # (csrc/attention.hip)
+            want = self.tap is not None and bool(self.tap["has_cls"]) and t >= 2
+            out_flat, imp = get_ops().attention_fwd(qkv_flat, self.num_heads, self.head_dim, self.scale, want)
+            if self.tap is not None:
+                if want:
+                    self.tap["out"] = imp
+                else:
+                    q_, k_, _ = qkv_flat.reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
+                    self.tap["out"] = self._importance(q_, k_, self.tap["has_cls"])
+            return self.proj(out_flat)
         qkv = qkv_flat.reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
         if self.tap is not None:
