@@ -416,3 +416,26 @@ def test_attention_fwd_matches_sdpa(nat, B, T, H):
         assert torch.allclose(imp.cpu(), want, rtol=2e-2, atol=1e-6)
         if T <= 256:
             assert torch.allclose(imp, nat.cls_importance(qkv.cuda(), H, hd, scale), rtol=2e-2, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,n", [(192, 192), (100, 100), (60, 50), (40, 10), (96, 21)])
+def test_jacobi_block_ordering_large_batch(nat, m, n):
+    """batches >= 512 take the block-ordering kernel (two columns per side and slot): singular values,
+    orthogonality of the rotated columns and the invariance of A A^T, incl. an odd number of blocks"""
+    batch = 512
+    g = torch.Generator().manual_seed(m * 31 + n)
+    a = torch.randn(batch, m, n, generator=g) * torch.logspace(0, -3, n).unsqueeze(0).unsqueeze(0)
+    ld = nat.jacobi_ld(m)
+    w = _colmajor(a.cuda(), ld)
+    sigma, sweeps = nat.jacobi_svd(w, m)
+    ref = torch.linalg.svdvals(a[:16].double())
+    assert torch.allclose(sigma[:16].cpu().double(), ref, rtol=3e-5, atol=1e-6 * float(ref.max()))
+    assert int(sweeps.max()) < 30
+    cols = w[:16, :, :m].cpu().double()                       # [b, n, m] rotated columns, sorted by norm
+    gram = cols @ cols.transpose(1, 2)
+    off = gram - torch.diag_embed(torch.diagonal(gram, dim1=1, dim2=2))
+    scale = torch.sqrt(torch.diagonal(gram, dim1=1, dim2=2).unsqueeze(2) * torch.diagonal(gram, dim1=1, dim2=2).unsqueeze(1))
+    assert float((off.abs() / scale.clamp_min(1e-30)).max()) < 2e-5
+    aat = a[:16].double() @ a[:16].double().transpose(1, 2)
+    assert torch.allclose(cols.transpose(1, 2) @ cols, aat, rtol=0, atol=2e-5 * float(aat.abs().max()))
+    assert float(w[:, :, m:].abs().max()) == 0.0 if ld > m else True

@@ -10,6 +10,7 @@
 // DPP (no LDS traffic), every lane computes the rotation redundantly and
 // writes its rows back.  Pairs of a step are disjoint (round-robin "circle"
 // ordering), one workgroup barrier per step.
+#include <stdlib.h>
 #include "basd_common.h"
 
 namespace basd {
@@ -409,6 +410,247 @@ __attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Block ordering (default for large batches): the hand-over chain (write -> wait -> barrier ->
+// read -> wait -> barrier, walked in lockstep by every wave) is two thirds of a step of the kernel
+// above and does not depend on the bytes moved (ablations).  Here a slot owns
+// two BLOCKS of two columns, P = (c0, c1) and Q = (c2, c3); the blocks travel along the odd-even
+// transposition line exactly like the single columns above, but every meeting of two blocks performs
+// all four cross rotations -- (c0,c2),(c1,c3) then (c0,c3),(c1,c2), two independent rotations at a
+// time -- before ONE hand-over of a whole block: four rotations per hand-over instead of one.  The
+// pair inside a block is rotated once per sweep.  One matrix per 8 * S-thread workgroup (S = slots =
+// a quarter of the columns: 384 threads at n = 192, 96 column VGPRs), single mailbox (74 KB): two
+// independent workgroups per CU, so one's hand-over overlaps the other's rotations.
+template <int MAXCH>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void jacobi_blk_kernel(
+    float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
+    float* __restrict__ sigma, int32_t* __restrict__ sweeps_out) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int LDC = 32 * MAXCH;                  // one column in the mailbox
+  constexpr int LDB = 2 * LDC;                     // one block
+  const int tid = threadIdx.x;
+  const int k = tid >> 3, sub = tid & 7, roff = sub * 4;
+  const int nb = (n + 1) >> 1;                     // blocks that hold real columns
+  const int nbe = nb + (nb & 1);                   // line length in blocks (a zero phantom block pads odd nb)
+  const int S = nbe >> 1;                          // slots
+  float* mbox = lds;                               // [S + 1][LDB]
+  float* s_sig = mbox + (size_t)(S + 1) * LDB;     // [4 S]
+  int* s_rank = reinterpret_cast<int*>(s_sig + 264);      // [4 S]
+  int* s_id = s_rank + 264;                        // [S][2] column ids travelling with the mailbox
+  float* s_nrm = reinterpret_cast<float*>(s_id + 264);    // [S][2] squared norms travelling along
+  int* s_flag = reinterpret_cast<int*>(s_nrm + 264);      // [2]
+
+  const int mat = blockIdx.x;
+  float* src = wg + (size_t)mat * n * ld;
+  const int mr = (m + 3) & ~3;
+  const bool live = k < S;
+  v4f C[4][MAXCH];
+  int id[4];
+  float nr[4];                                     // squared column norms (rotation identities inside a sweep)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    id[c] = 4 * k + c;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      const int r = roff + 32 * ch;
+      C[c][ch] = (live && id[c] < n && r < mr) ? *reinterpret_cast<const v4f*>(src + (size_t)id[c] * ld + r)
+                                               : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (tid < 2) s_flag[tid] = 0;
+  __syncthreads();
+
+  const float tol2 = tol * tol;
+  bool rotated = false;
+  // one plane rotation of the column pair (A, B); the caller issues two independent ones back to back
+  auto rot1 = [&](v4f (&A)[MAXCH], v4f (&B)[MAXCH], float& na, float& nb_, bool ok) {
+    float ga = 0.f, gb = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      const v4f x = A[ch], y = B[ch];
+      ga = fmaf(x.x, y.x, fmaf(x.y, y.y, ga));
+      gb = fmaf(x.z, y.z, fmaf(x.w, y.w, gb));
+    }
+    const float g = group8_sum(ga + gb);
+    const float al = na, be = nb_;
+    if (ok && g * g > tol2 * al * be && g != 0.f) {
+      rotated = true;
+      const float z = (be - al) * __builtin_amdgcn_rcpf(2.f * g);
+      const float t = copysignf(1.f, z) * __builtin_amdgcn_rcpf(fabsf(z) + __builtin_amdgcn_sqrtf(fmaf(z, z, 1.f)));
+      const float w = fmaf(t, t, 1.f);
+      float c = __builtin_amdgcn_rsqf(w);
+      c = c * fmaf(-0.5f * w, c * c, 1.5f);
+      const float sn = c * t;
+      const float u = sn * __builtin_amdgcn_rcpf(1.0f + c);
+      na = fmaf(-t, g, al);
+      nb_ = fmaf(t, g, be);
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) {
+        const v4f x = A[ch], y = B[ch];
+        v4f nx, ny;
+        nx.x = fmaf(-sn, fmaf(u, x.x, y.x), x.x); ny.x = fmaf(sn, fmaf(-u, y.x, x.x), y.x);
+        nx.y = fmaf(-sn, fmaf(u, x.y, y.y), x.y); ny.y = fmaf(sn, fmaf(-u, y.y, x.y), y.y);
+        nx.z = fmaf(-sn, fmaf(u, x.z, y.z), x.z); ny.z = fmaf(sn, fmaf(-u, y.z, x.z), y.z);
+        nx.w = fmaf(-sn, fmaf(u, x.w, y.w), x.w); ny.w = fmaf(sn, fmaf(-u, y.w, x.w), y.w);
+        A[ch] = nx; B[ch] = ny;
+      }
+    }
+  };
+  auto rot2 = [&](v4f (&A0)[MAXCH], v4f (&B0)[MAXCH], float& na0, float& nb0, v4f (&A1)[MAXCH], v4f (&B1)[MAXCH],
+                  float& na1, float& nb1, bool ok) {
+    rot1(A0, B0, na0, nb0, ok);
+    __builtin_amdgcn_sched_barrier(0);             // keep the register live ranges of the inlined copies apart
+    rot1(A1, B1, na1, nb1, ok);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int used_sweeps = 0;
+  int step = 0;                                    // even = blocks (2k, 2k+1); nbe is even, sweeps start and end there
+#pragma unroll 1
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    rotated = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                  // exact squared norms once per sweep
+      float a = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) {
+        const v4f x = C[c][ch];
+        a = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, a))));
+      }
+      nr[c] = group8_sum(a);
+    }
+    rot2(C[0], C[1], nr[0], nr[1], C[2], C[3], nr[2], nr[3], live);       // the pair inside each block
+#pragma unroll 1
+    for (int t = 0; t < nbe; ++t, ++step) {
+      const bool even_view = (step & 1) == 0;
+      const bool pair_ok = live && (even_view || k < S - 1);
+      rot2(C[0], C[2], nr[0], nr[2], C[1], C[3], nr[1], nr[3], pair_ok);
+      rot2(C[0], C[3], nr[0], nr[3], C[1], C[2], nr[1], nr[2], pair_ok);
+      // ---- hand one block over (after the logical swap the pair is stored as (lo = Q, hi = P)):
+      // even -> odd view: Q (block position 2k) goes to slot k-1, slot 0's copy stays parked in box 0;
+      // odd -> even view: P (position 2k+2; the lone last slot did not swap) goes to slot k+1.
+      // Register loads are the same for every live slot (a block copied or loaded under a per-slot condition
+      // makes the register allocator spill hundreds of VGPRs); only the LDS writes are conditional.
+      if (even_view) {
+        // Q (block position 2k after the swap) goes to slot k-1 through box k (slot 0's stays parked there);
+        // the last slot has no right neighbour: it parks its P in box S and takes it back as Q, which is
+        // where its lone block of the odd view has to sit for the next even view
+        if (live) {
+          float* box = mbox + (size_t)k * LDB + roff;
+#pragma unroll
+          for (int ch = 0; ch < MAXCH; ++ch) {
+            *reinterpret_cast<v4f*>(box + 32 * ch) = C[2][ch];
+            *reinterpret_cast<v4f*>(box + LDC + 32 * ch) = C[3][ch];
+          }
+          if (sub == 0) { s_id[2 * k] = id[2]; s_id[2 * k + 1] = id[3]; s_nrm[2 * k] = nr[2]; s_nrm[2 * k + 1] = nr[3]; }
+          if (k == S - 1) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) {
+              *reinterpret_cast<v4f*>(box + LDB + 32 * ch) = C[0][ch];
+              *reinterpret_cast<v4f*>(box + LDB + LDC + 32 * ch) = C[1][ch];
+            }
+            if (sub == 0) { s_id[2 * k + 2] = id[0]; s_id[2 * k + 3] = id[1]; s_nrm[2 * k + 2] = nr[0]; s_nrm[2 * k + 3] = nr[1]; }
+          }
+        }
+        __syncthreads();
+        if (live) {
+          const float* box = mbox + (size_t)(k + 1) * LDB + roff;
+#pragma unroll
+          for (int ch = 0; ch < MAXCH; ++ch) {
+            C[2][ch] = *reinterpret_cast<const v4f*>(box + 32 * ch);
+            C[3][ch] = *reinterpret_cast<const v4f*>(box + LDC + 32 * ch);
+          }
+          id[2] = s_id[2 * k + 2]; id[3] = s_id[2 * k + 3];
+          nr[2] = s_nrm[2 * k + 2]; nr[3] = s_nrm[2 * k + 3];
+        }
+      } else {
+        // P (position 2k+2 after the swap) goes to slot k+1 through box k+1; slot 0 takes the parked block back
+        if (live && k < S - 1) {
+          float* box = mbox + (size_t)(k + 1) * LDB + roff;
+#pragma unroll
+          for (int ch = 0; ch < MAXCH; ++ch) {
+            *reinterpret_cast<v4f*>(box + 32 * ch) = C[0][ch];
+            *reinterpret_cast<v4f*>(box + LDC + 32 * ch) = C[1][ch];
+          }
+          if (sub == 0) { s_id[2 * k + 2] = id[0]; s_id[2 * k + 3] = id[1]; s_nrm[2 * k + 2] = nr[0]; s_nrm[2 * k + 3] = nr[1]; }
+        }
+        __syncthreads();
+        if (live) {
+          const float* box = mbox + (size_t)k * LDB + roff;
+#pragma unroll
+          for (int ch = 0; ch < MAXCH; ++ch) {
+            C[0][ch] = *reinterpret_cast<const v4f*>(box + 32 * ch);
+            C[1][ch] = *reinterpret_cast<const v4f*>(box + LDC + 32 * ch);
+          }
+          id[0] = s_id[2 * k]; id[1] = s_id[2 * k + 1];
+          nr[0] = s_nrm[2 * k]; nr[1] = s_nrm[2 * k + 1];
+        }
+      }
+      __syncthreads();                             // single mailbox: reads done before the next writes
+    }
+    used_sweeps = sweep + 1;
+    if (rotated) s_flag[sweep & 1] = 1;
+    __syncthreads();
+    const int any = s_flag[sweep & 1];
+    if (tid == 0) s_flag[(sweep + 1) & 1] = 0;
+    __syncthreads();
+    if (!any) break;
+  }
+
+  // ---- singular values = column norms over the first norm_rows rows; phantom columns (id >= n) rank last
+  {
+    float a[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) {
+        const int r = roff + 32 * ch;
+        const float mx = (r + 0 < norm_rows) ? 1.f : 0.f, my = (r + 1 < norm_rows) ? 1.f : 0.f;
+        const float mz = (r + 2 < norm_rows) ? 1.f : 0.f, mw = (r + 3 < norm_rows) ? 1.f : 0.f;
+        const v4f x = C[c][ch];
+        acc = fmaf(mx * x.x, x.x, fmaf(my * x.y, x.y, fmaf(mz * x.z, x.z, fmaf(mw * x.w, x.w, acc))));
+      }
+      a[c] = group8_sum(acc);
+    }
+    if (live && sub == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_sig[4 * k + c] = (id[c] >= n) ? -1.f : sqrtf(a[c]);
+    }
+  }
+  __syncthreads();
+  const int n_tot = 4 * S;                         // >= n; positions beyond the real columns hold -1
+  for (int p = tid; p < n_tot; p += blockDim.x) {
+    int rank = p;
+    if (sort) {
+      const float mine = s_sig[p];
+      rank = 0;
+      for (int c = 0; c < n_tot; ++c) {
+        const float o = s_sig[c];
+        rank += (o > mine) || (o == mine && c < p);
+      }
+    }
+    s_rank[p] = rank;
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int d = sort ? s_rank[4 * k + c] : id[c];
+      const float sg = s_sig[4 * k + c];
+      if (id[c] < n && d < n) {
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+          const int r = roff + 32 * ch;
+          if (r < ld) *reinterpret_cast<v4f*>(src + (size_t)d * ld + r) = (r < mr) ? C[c][ch] : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        if (sub == 0) sigma[(size_t)mat * n + d] = sg < 0.f ? 0.f : sg;
+      }
+    }
+  }
+  if (sweeps_out && tid == 0) sweeps_out[mat] = used_sweeps;
+}
+
 }  // namespace basd
 
 extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
@@ -437,6 +679,24 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
                        n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows); \
   } while (0)
+  static const bool column_ordering = getenv("BASD_JACOBI_COLUMNS") != nullptr;   // debugging aid: previous kernels
+  if (!column_ordering && active == nullptr && batch >= 512 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
+    // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
+    const int nbk = (n_cols + 1) / 2, slots = (nbk + 1) / 2;
+    const int threads_b = ((slots * 8 + 63) / 64) * 64;
+    const size_t lds_b = ((size_t)(slots + 1) * 2 * 32 * oe_ch + 264 * 4 + 8) * 4;
+#define BASD_LAUNCH_BLK(MC)                                                                          \
+  do {                                                                                               \
+    allow_full_lds((const void*)jacobi_blk_kernel<MC>);                                              \
+    hipLaunchKernelGGL((jacobi_blk_kernel<MC>), dim3(batch), dim3(threads_b), lds_b, st, w, batch, m_rows, n_cols, \
+                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps);                         \
+  } while (0)
+    if (oe_ch == 2) BASD_LAUNCH_BLK(2);
+    else if (oe_ch == 4) BASD_LAUNCH_BLK(4);
+    else BASD_LAUNCH_BLK(6);
+#undef BASD_LAUNCH_BLK
+    return check_launch("jacobi_svd (block odd-even)");
+  }
   if (fits && batch >= 512 && npairs <= 96 && oe_ch <= 6) {
     const int grid2 = (batch + 1) / 2;
     if (oe_ch == 2) BASD_LAUNCH_OE(2, 2, grid2, lds_oe2);
