@@ -175,7 +175,7 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
-        # ---- roofline of the dominant hand-written kernel: the LDS-resident one-sided Jacobi.
+        # ---- roofline of the dominant hand-written kernel: the register-resident one-sided Jacobi (block ordering).
         # It is neither HBM- nor MFMA-bound (LDS/VALU-bound); it is priced against the
         # fp32 vector/matrix peak (157.3 TF, equal on gfx950) with ALGORITHMIC flops =
         # sweeps_nominal * n(n-1)/2 pairs * 14 m flops (3 dots of length m + a 4-FMA rotation of two
@@ -198,12 +198,12 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
                     for key, v in json.load(f)["kernels"].items():
-                        if key.startswith("jacobi_oe_kernel<6, 2>"):
+                        if key.startswith("basd::jacobi_blk_kernel<6>"):
                             traffic = v["hbm_bytes_per_launch"]
             except OSError:
                 pass
-            roof = {"kernel": "basd::jacobi_oe_kernel<6,2> (register-resident one-sided Jacobi, the E*B = 1024 Procrustes "
-                              "cores of a step, 192x192 each)",
+            roof = {"kernel": "basd::jacobi_blk_kernel<6> (register-resident one-sided Jacobi, block odd-even ordering, the "
+                              "E*B = 1024 Procrustes cores of a step, 192x192 each)",
                     "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                     "frac": achieved / 157.3, "traffic": traffic,
                     "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / probe_steps,
@@ -212,7 +212,7 @@ def main():
                                     f"{probe_steps} instrumented eager steps of the same process before the timed region "
                                     "(the timed steps replay one hipGraph; device events cannot be recorded inside it; "
                                     "rocprofv3 of the same command sees the graph-launched kernels: profiles/)"),
-                    "note": "LDS/VALU-bound kernel priced against the fp32 vector = matrix peak; algorithmic flops = "
+                    "note": "VALU-issue-bound kernel priced against the fp32 vector = matrix peak; algorithmic flops = "
                             "8 sweeps x n(n-1)/2 pairs x 14 m per matrix (DESIGN.md section 5)"}
         vit_flops = global_batch * ((4 if args.grad_checkpointing else 3) * F_STUDENT + F_TEACHER)
         cpu = None
