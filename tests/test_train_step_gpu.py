@@ -73,3 +73,24 @@ def test_packed_attention_matches_plain_sdpa():
     assert torch.equal(y1, y2)
     assert torch.allclose(gx1.float(), x.grad.float(), rtol=2e-2, atol=2e-3)
     assert torch.allclose(gw1.float(), attn.qkv.weight.grad.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_fused_teacher_blocks_match_library_path(monkeypatch):
+    """frozen teacher: fused residual-add + LayerNorm and the fused attention kernel (+ tap) against the
+    library path (torch adds, separate LayerNorm launches, SDPA, stand-alone tap) on the same weights"""
+    import basd_amd.models.vit as V
+    from basd_amd.models.teacher import extract_intermediates, load_teacher
+    teacher = load_teacher("vit_base_patch16_224", 224, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    tok_f, imp_f = extract_intermediates(teacher, x)
+    monkeypatch.setattr(V, "_FUSED_TEACHER_ATTENTION", False)
+    monkeypatch.setattr(V.Block, "_fused_inference", lambda self, x: False)
+    tok_l, imp_l = extract_intermediates(teacher, x)
+    assert sorted(tok_f) == sorted(tok_l)
+    for j in tok_f:
+        a, b = tok_f[j].float(), tok_l[j].float()
+        # bf16 activations: the two attention kernels round P / accumulate in different orders
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 1.5e-2, (j, rel)
+        assert torch.allclose(imp_f[j], imp_l[j], rtol=5e-2, atol=2e-5), j
+        assert abs(float(imp_f[j].sum(-1).mean()) - float(imp_l[j].sum(-1).mean())) < 1e-3
