@@ -86,7 +86,13 @@ def importance_from_attention(attn: torch.Tensor, has_cls_token: bool) -> torch.
 # selector weights
 # --------------------------------------------------------------------------- #
 @torch.no_grad()
-def teacher_frames(teacher_tokens, proj_t):
+def teacher_gram(tokens, proj_t):
+    """(uncentred Gram [D, D] fp64 lower triangle, column sums [D] fp64) of one teacher layer's projected tokens:
+    the per-layer piece of ``teacher_frames`` (can be launched as soon as the layer's block has run)."""
+    return get_ops().token_gram(tokens, proj_t, mirror=False)
+
+
+def teacher_frames(teacher_tokens, proj_t, grams=None):
     """Teacher half of the selector (no gradient): per-layer Gram statistics -> MP ranks (device
     int32, no host sync) and rank-masked PCA frames.  Reference layer_selector.py:69-74, 133-138.
 
@@ -98,8 +104,8 @@ def teacher_frames(teacher_tokens, proj_t):
     D = proj_t.shape[0]
     m_t = teacher_tokens[0].shape[0] * teacher_tokens[0].shape[1]
     unc, cen = [], []
-    for x in teacher_tokens:                            # layer_selector.py:71-73, :134-136
-        g, c = ops.token_gram(x, proj_t, mirror=False)  # [B, N, D] view, no copy; lower triangle
+    for i, x in enumerate(teacher_tokens):              # layer_selector.py:71-73, :134-136
+        g, c = grams[i] if grams is not None else ops.token_gram(x, proj_t, mirror=False)   # lower triangle
         unc.append(g)
         cen.append(g - torch.outer(c, c) / m_t)
     sigma, u, _ = psd_eig(torch.stack(unc + cen), lower_only=True)

@@ -73,22 +73,33 @@ class GrassmannianLayerSelector(nn.Module):
             return {}
         return dict(zip(self._rank_keys, self._ranks_dev.tolist()))
 
-    def precompute_teacher(self, all_teacher_tokens) -> None:
+    def teacher_layer_gram(self, tokens):
+        """Gram statistics of ONE teacher layer (to be handed to ``precompute_teacher(..., grams=...)``): lets a
+        caller launch them layer by layer while the teacher forward is still running."""
+        return BF.teacher_gram(tokens.detach(), self.proj_t)
+
+    def precompute_teacher(self, all_teacher_tokens, grams=None, also_wait=()) -> None:
         """Optional: run the teacher half of the selector (Gram statistics, MP ranks, PCA frames) ahead
         of ``forward`` -- e.g. on a side stream while the student forward runs.  Consumed by the next
-        ``mixing_weights`` / ``forward`` call."""
+        ``mixing_weights`` / ``forward`` call.  ``grams``: {layer: teacher_layer_gram(...)} computed earlier;
+        ``also_wait``: further CUDA events the consumer has to wait for (e.g. the end of the teacher forward
+        when this runs on a different stream)."""
         teacher_indices = sorted(all_teacher_tokens.keys())
-        frames = BF.teacher_frames([all_teacher_tokens[j].detach() for j in teacher_indices], self.proj_t)
+        frames = BF.teacher_frames([all_teacher_tokens[j].detach() for j in teacher_indices], self.proj_t,
+                                   grams=None if grams is None else [grams[j] for j in teacher_indices])
         if self.proj_t.is_cuda:
             # produced on the caller's current (possibly side) stream: the consumer joins it through this
             # event at the point of use, after its own student statistics have been enqueued
             done = torch.cuda.Event()
             done.record()
             tensors = [t for t in frames.values() if isinstance(t, torch.Tensor)]
+            extra = list(also_wait)
 
             def ready():
                 cur = torch.cuda.current_stream()
                 cur.wait_event(done)
+                for ev in extra:
+                    cur.wait_event(ev)
                 if not torch.cuda.is_current_stream_capturing():
                     for t in tensors:
                         t.record_stream(cur)

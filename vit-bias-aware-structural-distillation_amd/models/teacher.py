@@ -161,8 +161,10 @@ def estimate_intrinsic_dim(teacher: TeacherModel, images: torch.Tensor) -> int:
 
 
 @torch.no_grad()
-def extract_intermediates(teacher: TeacherModel, x: torch.Tensor):
-    """-> (tokens {j: [B,N,D]}, importance {j: [B,N]}); CNN teachers: one layer, uniform importance."""
+def extract_intermediates(teacher: TeacherModel, x: torch.Tensor, on_layer=None):
+    """-> (tokens {j: [B,N,D]}, importance {j: [B,N]}); CNN teachers: one layer, uniform importance.
+    ``on_layer(j, tokens_j)`` is called from the block's forward hook, i.e. as soon as layer j's tokens have been
+    enqueued (the trainer launches that layer's selector statistics on another stream from it)."""
     x = x.to(next(teacher.model.parameters()).dtype)
     if teacher.feature_format != "token":
         feats = _to_token_format(teacher.model.forward_features(x), teacher.feature_format, teacher.has_cls_token)
@@ -177,6 +179,8 @@ def extract_intermediates(teacher: TeacherModel, x: torch.Tensor):
             def hook(mod, inp, out):
                 # a view of the block output (CLS stripped by offset): the kernels take batch-strided views
                 tokens[i] = _to_token_format(out, teacher.feature_format, teacher.has_cls_token)
+                if on_layer is not None:
+                    on_layer(i, tokens[i])
             return hook
         hooks.append(module.register_forward_hook(make_token_hook(idx)))
         if teacher.attn_subpath is not None:
