@@ -116,20 +116,31 @@ def teacher_frames(teacher_tokens, proj_t, grams=None):
     return {"ranks": ranks, "keep": keep, "vm_t": v_t * keep.unsqueeze(-1), "sw": s_t * keep}
 
 
+@torch.no_grad()
+def student_frames(student_tokens, proj_s):
+    """Student half of the selector statistics (centred Gram eigen-decomposition per extraction point):
+    (sigma [E, D], v [E, D, D]).  No gradient flows through these tensors themselves -- the selector backward
+    differentiates the eigen-decomposition analytically from them -- so a trainer may compute them ahead of the
+    loss (reference layer_selector.py:84-92)."""
+    ops = get_ops()
+    mats = []
+    m_s = student_tokens[0].shape[0] * student_tokens[0].shape[1]
+    for s in student_tokens:
+        g, c = ops.token_gram(s.detach(), proj_s, mirror=False)
+        mats.append(g - torch.outer(c, c) / m_s)
+    sigma_s, v_s, _ = psd_eig(torch.stack(mats), lower_only=True)
+    return sigma_s, v_s
+
+
 class _SelectorWeightsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_temp, proj_s, ranks, keep, vm_t, sw, ready, *student):
+    def forward(ctx, log_temp, proj_s, ranks, keep, vm_t, sw, ready, pre_s, *student):
         ops = get_ops()
         E, L = len(student), vm_t.shape[0]
         D = proj_s.shape[0]
         dev = proj_s.device
 
-        mats = []
-        m_s = student[0].shape[0] * student[0].shape[1]
-        for s in student:                               # layer_selector.py:84-92
-            g, c = ops.token_gram(s, proj_s, mirror=False)
-            mats.append(g - torch.outer(c, c) / m_s)
-        sigma_s, v_s, _ = psd_eig(torch.stack(mats), lower_only=True)
+        sigma_s, v_s = pre_s if pre_s is not None else student_frames(student, proj_s)
         lam_s = sigma_s.double() ** 2
         if ready is not None:
             ready()           # join the stream that produced the teacher frames only now: the student's own
@@ -191,18 +202,19 @@ class _SelectorWeightsFn(torch.autograd.Function):
             # centring z = s P^T over rows == centring s (linear map), so d loss / d s = (s - mean) W
             centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
             grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
-        return (g_lt, None, None, None, None, None, None, *grads)
+        return (g_lt, None, None, None, None, None, None, None, *grads)
 
 
-def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_temperatures, frames=None):
+def selector_weights(student_tokens, teacher_tokens, proj_s, proj_t, log_temperatures, frames=None, pre_student=None):
     """-> (weights [E, L] with grad, ranks int32 [L] on device, pre_softmax [E, L]).
 
-    ``frames`` = a ``teacher_frames`` result computed earlier (e.g. on a side stream)."""
+    ``frames`` = a ``teacher_frames`` result computed earlier (e.g. on a side stream);
+    ``pre_student`` = a ``student_frames`` result for exactly these student tokens."""
     if frames is None:
         frames = teacher_frames([t.detach() for t in teacher_tokens], proj_t)
     # batch-strided views (CLS-stripped block outputs) are consumed in place
     wts, pre = _SelectorWeightsFn.apply(log_temperatures, proj_s, frames["ranks"], frames["keep"], frames["vm_t"],
-                                        frames["sw"], frames.get("ready"), *student_tokens)
+                                        frames["sw"], frames.get("ready"), pre_student, *student_tokens)
     return wts, frames["ranks"], pre
 
 

@@ -73,6 +73,12 @@ class GrassmannianLayerSelector(nn.Module):
             return {}
         return dict(zip(self._rank_keys, self._ranks_dev.tolist()))
 
+    def precompute_student(self, student_tokens_per_layer, extraction_indices) -> None:
+        """Optional: the student half of the selector statistics ahead of ``forward`` (consumed by the next
+        ``mixing_weights`` call for the same token tensors)."""
+        toks = [student_tokens_per_layer[l] for l in extraction_indices]
+        self._student_pre = ([id(t) for t in toks], BF.student_frames(toks, self.proj_s))
+
     def teacher_layer_gram(self, tokens):
         """Gram statistics of ONE teacher layer (to be handed to ``precompute_teacher(..., grams=...)``): lets a
         caller launch them layer by layer while the teacher forward is still running."""
@@ -115,10 +121,13 @@ class GrassmannianLayerSelector(nn.Module):
             elif "ready" in self._frames[1]:
                 self._frames[1]["ready"]()           # unused precomputation: still join its stream
         self._frames = None
+        s_list = [student_tokens_per_layer[l] for l in extraction_indices]
+        pre_s, self._student_pre = getattr(self, "_student_pre", None), None
+        if pre_s is not None:
+            pre_s = pre_s[1] if pre_s[0] == [id(t) for t in s_list] else None
         weights, ranks, pre = BF.selector_weights(
-            [student_tokens_per_layer[l] for l in extraction_indices],
-            [all_teacher_tokens[j] for j in teacher_indices],
-            self.proj_s, self.proj_t, self.log_temperatures, frames=frames)
+            s_list, [all_teacher_tokens[j] for j in teacher_indices],
+            self.proj_s, self.proj_t, self.log_temperatures, frames=frames, pre_student=pre_s)
         self._ranks_dev, self._rank_keys = ranks, teacher_indices
         self.last_weights, self.last_pre_softmax = weights.detach(), pre.detach()
         return weights, teacher_indices

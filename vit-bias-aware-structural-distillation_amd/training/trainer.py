@@ -81,18 +81,9 @@ class Trainer:
         self.autocast_dtype = torch.bfloat16
         self.overlap_teacher_stats = True
         self.overlap_teacher_forward = os.environ.get("BASD_OVERLAP_TEACHER", "1") == "1"
-        # per-layer teacher Gram statistics on a third stream underneath the remaining teacher blocks: measured
-        # 0.9 ms SLOWER per step inside the captured graph (same-box A/B) -- off
-        self.layerwise_teacher_stats = os.environ.get("BASD_LAYERWISE_STATS", "0") == "1"
         self._side = None
-        self._stats = None
         self._graph = None
         self.graph_error = None
-
-    def _stats_stream(self):
-        if self._stats is None:
-            self._stats = torch.cuda.Stream(device=self.device)
-        return self._stats
 
     def _side_stream(self):
         if self.device.type != "cuda" or not self.overlap_teacher_stats:
@@ -112,51 +103,36 @@ class Trainer:
         # otherwise only the statistics do.
         side = self._side_stream()
         capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        selector = self.basd_loss.layer_selector
+
+        def student_forward():
+            with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
+                return _extract_student(self.model, student_imgs, self.basd_loss.token_layers,
+                                        layer_paths=self._student_layer_paths, has_cls_token=self._student_has_cls)
+
         if side is not None and self.overlap_teacher_forward:
+            # Measured and rejected inside the captured graph (same-box A/B, ms per step): the teacher's Gram passes
+            # layer by layer on a third stream +0.9; the same on THIS stream behind the student forward, one event per
+            # layer, +3.7.  The graph executor does best with two coarse branches.
             main = torch.cuda.current_stream()
             side.wait_stream(main)
-            selector = self.basd_loss.layer_selector
-            stats = self._stats_stream()
-            grams = {}
-
-            def on_layer(j, tok):
-                # layer j's Gram statistics on a third stream, underneath the remaining teacher blocks: only the
-                # (latency-bound) eigen-solve of all layers is left for the end of the branch
-                ev = torch.cuda.Event()
-                ev.record(side)
-                stats.wait_event(ev)
-                with torch.cuda.stream(stats):
-                    grams[j] = selector.teacher_layer_gram(tok)
-
-            if self.layerwise_teacher_stats:
-                with torch.cuda.stream(side):
-                    t_tokens, t_importance = extract_intermediates(self._teacher, clean, on_layer=on_layer)
-                    fwd_done = torch.cuda.Event()
-                    fwd_done.record(side)
-                with torch.cuda.stream(stats):
-                    selector.precompute_teacher(t_tokens, grams=grams, also_wait=(fwd_done,))
-            else:
-                with torch.cuda.stream(side):
-                    t_tokens, t_importance = extract_intermediates(self._teacher, clean)
-                    selector.precompute_teacher(t_tokens)
+            with torch.cuda.stream(side):
+                t_tokens, t_importance = extract_intermediates(self._teacher, clean)
+                selector.precompute_teacher(t_tokens)
+            logits, s_tokens = student_forward()
         else:
             t_tokens, t_importance = extract_intermediates(self._teacher, clean)
             if side is not None:
                 main = torch.cuda.current_stream()
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    self.basd_loss.layer_selector.precompute_teacher(t_tokens)
-        with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
-            logits, s_tokens = _extract_student(
-                self.model, student_imgs, self.basd_loss.token_layers,
-                layer_paths=self._student_layer_paths, has_cls_token=self._student_has_cls)
+                    selector.precompute_teacher(t_tokens)
+            logits, s_tokens = student_forward()
         # no join here: the selector waits for the side stream (event recorded by precompute_teacher) only
         # where it consumes the teacher frames, so the student's statistics overlap the teacher's
         loss = self.basd_loss(logits.float(), mixed_targets, s_tokens, t_tokens, t_importance)
         if side is not None and self.basd_loss.layer_selector._frames is not None:
             main.wait_stream(side)               # the loss did not consume the precomputation: join anyway
-            if self._stats is not None:
-                main.wait_stream(self._stats)
             self.basd_loss.layer_selector._frames = None
         if side is not None and self.overlap_teacher_forward and not capturing:
             # eager mode: the teacher outputs were allocated on the side stream and are read on this one
