@@ -24,6 +24,17 @@
  *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
  *   basd_wgrad_bf16        autograd of the student's timm nn.Linear layers (trainer.py:157)
  *   basd_sf_adamw_step     schedulefree.AdamWScheduleFree.step  src/training/trainer.py:54-58,158
+ *   basd_bgemm_f64, basd_trinv_f64
+ *                          the products / triangular solves around the SVD of relational.py:47-48 and its backward
+ *                          (torch.linalg.svd backward -> U V^T), formed in fp64
+ *   basd_procrustes_bwd_rows
+ *                          autograd of relational.py:29-46 (centring, sqrt-weights, traces)
+ *   basd_attention_fwd_bf16, basd_cls_importance_bf16
+ *                          timm Attention.forward of the frozen teacher (teacher.py:118 creates it) and the
+ *                          attention capture hook src/models/teacher.py:27-39 + relational.py:22-27
+ *   basd_layernorm_fwd_bf16 / _bwd_bf16, basd_add_layernorm_fwd_bf16
+ *                          timm nn.LayerNorm of the ViT blocks (student: with backward; frozen teacher: fused with
+ *                          the residual add in front of it)
  */
 #ifndef BASD_HIP_H
 #define BASD_HIP_H
