@@ -61,6 +61,10 @@ SHAPES = {
     # BASELINE config c2 loss shapes at reduced batch (full-rank Procrustes: 195 >= 192)
     "c2_b8": Shape(B=8, N_s=196, N_t=196, D_s=192, D_t=768, L_t=12, H=12, C=1000,
                    r0=8, dr=4, decay=0.97),
+    # BASELINE config c3 loss shapes at reduced batch: CNN teacher = one "layer" of 7x7 = 49 tokens x 2048
+    # channels, uniform attention, resampled 49 -> 196 ("c3 degenerates, exactly")
+    "c3_b4": Shape(B=4, N_s=196, N_t=49, D_s=192, D_t=2048, L_t=1, H=1, C=1000, has_cls=False,
+                   r0=8, dr=4, decay=0.97),
 }
 
 

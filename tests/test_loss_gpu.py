@@ -64,6 +64,16 @@ def test_c2_shapes_full_parity():
         assert abs(float(res[f"grad_student_{l}"].double().norm()) - n_ref) <= 5e-4 * n_ref
 
 
+def test_c3_shapes_cnn_teacher_parity():
+    """BASELINE c3 loss shapes (B reduced): single-layer CNN teacher, 49 -> 196 token resample, D_t = 2048"""
+    shape, inputs, gold = load("c3_b4")
+    res = run_basd_loss(shape, inputs, gold, "hard", device="cuda")
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-4)
+    for l in inputs["token_layers"]:
+        n_ref = float(gold[f"hard/grad_student_{l}_norm"])
+        assert abs(float(res[f"grad_student_{l}"].double().norm()) - n_ref) <= 5e-4 * n_ref
+
+
 def test_bf16_tokens_close_to_fp32_path():
     # production feeds bf16 activations; compare with the same values pre-rounded to bf16
     shape, inputs, gold = load("tiny")
