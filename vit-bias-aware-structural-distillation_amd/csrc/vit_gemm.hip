@@ -9,9 +9,11 @@
 // read ROW-major exactly once per tile column/row (coalesced 16-byte loads) and the MFMA
 // fragments, which need 8 consecutive m for a fixed n (or k), come out of LDS through the
 // gfx950 transposing read ds_read_b64_tr_b16 -- no transposed copy of the activations.
-// Workgroup = 256 threads = 4 waves; output tile 64 (n) x TK (k, up to 192), wave w owns
-// n rows [16 w, 16 w + 16); per 64-row chunk: 2 k-steps of v_mfma_f32_16x16x32_bf16 per
-// k tile.  Partial results are added with fp32 atomics (dW / db zero-initialised by the caller).
+// Workgroup = 256 threads = 4 waves; output tile 64 (n) x TK (k, up to 192), wave w owns a
+// quarter of the k tiles and all four n tiles; per 64-row chunk: 2 k-steps of
+// v_mfma_f32_16x16x32_bf16 per (n, k) tile.  Partial results are added with fp32 atomics (dW / db
+// zero-initialised by the caller); the atomics are 27 % of the kernel (ablation), 512 workgroups
+// is the measured optimum between that tail and load parallelism.
 #include "basd_common.h"
 
 namespace basd {
@@ -51,9 +53,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const unsigned short* _
   int64_t m_end = m_begin + rows_per_slice;
   if (m_end > M) m_end = M;
 
-  f32x4 acc[KT];
+  // wave w owns the k tiles [KW w, KW w + KW) and ALL four n tiles: 4 + KW fragment reads per 32-row step for
+  // 4 KW MFMAs.  (Owning one n tile and all KT k tiles needs 1 + KT reads for the same KT MFMAs: every wave then
+  // re-reads the whole X chunk and the kernel is LDS-read bound, 830 cycles of ds_read_b64_tr per chunk against
+  // 384 cycles of MFMA.)
+  constexpr int KW = KT / 4;
+  f32x4 acc[4][KW];
 #pragma unroll
-  for (int t = 0; t < KT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < KW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   const bool do_bias = (db != nullptr) && (blockIdx.y == 0);
 
@@ -99,11 +108,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const unsigned short* _
 #pragma unroll
     for (int ks = 0; ks < WG_MC / 32; ++ks) {
       const int row0 = ks * 32 + 8 * (lane >> 4);
-      const bf16x8 a = tr_frag(dYs, DY_LD, row0, wave * 16, lane);
+      bf16x8 a[4];
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        const bf16x8 b = tr_frag(Xs, X_LD, row0, t * 16, lane);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) a[i] = tr_frag(dYs, DY_LD, row0, i * 16, lane);
+#pragma unroll
+      for (int t = 0; t < KW; ++t) {
+        const bf16x8 b = tr_frag(Xs, X_LD, row0, (wave * KW + t) * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][t], 0, 0, 0);
       }
     }
     if (do_bias && tid < WG_TN) {
@@ -115,13 +127,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const unsigned short* _
   }
   // C/D layout: col = lane & 15 (k), row = (lane >> 4) * 4 + reg (n)
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int n = n0 + wave * 16 + (lane >> 4) * 4 + reg;
-      const int k = k0 + t * 16 + (lane & 15);
-      atomicAdd(&dw[(size_t)n * K + k], acc[t][reg]);
-    }
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int n = n0 + i * 16 + (lane >> 4) * 4 + reg;
+        const int k = k0 + (wave * KW + t) * 16 + (lane & 15);
+        atomicAdd(&dw[(size_t)n * K + k], acc[i][t][reg]);
+      }
   if (do_bias && tid < WG_TN) atomicAdd(&db[n0 + tid], bsum);
 }
 
