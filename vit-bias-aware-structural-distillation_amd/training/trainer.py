@@ -168,9 +168,25 @@ class Trainer:
                     self.flat.zero_grad()
             torch.cuda.current_stream().wait_stream(warm)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._g_loss, self._g_logits = self._forward_backward(self._g_clean, self._g_imgs, self._g_targets)
+            # "global" capture mode (the default) lets an unsafe call from ANY thread -- e.g. an event query of the
+            # process group's watchdog thread -- invalidate the capture; retry once in thread-local mode before
+            # giving up on the graph
+            last = None
+            for mode in ("global", "thread_local"):
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, capture_error_mode=mode):
+                        self._g_loss, self._g_logits = self._forward_backward(self._g_clean, self._g_imgs,
+                                                                              self._g_targets)
+                    last = None
+                    break
+                except Exception as exc:
+                    last = exc
+                    self.basd_loss.layer_selector._frames = None
+                    torch.cuda.synchronize()
+                    self.flat.zero_grad()
+            if last is not None:
+                raise last
             self.flat.zero_grad()
             self._graph = graph
             return True
