@@ -61,7 +61,7 @@ class KernelTimer:
                 self.records[_name].append((s, e))
                 if _name == "jacobi_svd":
                     # (batch, n_cols, m_rows, rank-masked?) -- masked launches sweep a smaller block
-                    self.meta[_name].append((a[0].shape[0], a[0].shape[1], a[1], k.get("active") is not None, s, e))
+                    self.meta[_name].append((a[0].shape[0], a[0].shape[1], a[1], k.get("active") is not None, s, e, out[1]))
                 return out
             setattr(self.native, name, wrapped)
 
@@ -176,19 +176,24 @@ def main():
     if rank == 0:
         ks = timer.summary()
         # ---- roofline of the dominant hand-written kernel: the register-resident one-sided Jacobi (block ordering).
-        # It is neither HBM- nor MFMA-bound (LDS/VALU-bound); it is priced against the
+        # It is neither HBM- nor MFMA-bound (VALU-issue-bound); it is priced against the
         # fp32 vector/matrix peak (157.3 TF, equal on gfx950) with ALGORITHMIC flops =
-        # sweeps_nominal * n(n-1)/2 pairs * 14 m flops (3 dots of length m + a 4-FMA rotation of two
-        # columns), sweeps_nominal = 8.
+        # sweeps * n(n-1)/2 pairs * 14 m flops (3 dots of length m + a 4-FMA rotation of two
+        # columns), sweeps = what every matrix of the launch actually ran.
         roof = None
         if "jacobi_svd" in ks:
-            flops, tot_ms, launches = 0.0, 0.0, 0
+            flops, tot_ms, launches, sweep_sum, mats = 0.0, 0.0, 0, 0.0, 0
             big = max(b for (b, *_rest) in timer.meta["jacobi_svd"])
-            for (b, n, m, masked, ev_s, ev_e) in timer.meta["jacobi_svd"]:
+            for (b, n, m, masked, ev_s, ev_e, sweeps_t) in timer.meta["jacobi_svd"]:
                 if masked or b != big:
                     continue          # dominant launch only: the E*B Procrustes cores (the small selector launches
                                       # run on a side stream / sweep data-dependent blocks)
-                flops += b * 8 * (n * (n - 1) / 2) * 14.0 * m
+                # sweeps actually run by every matrix of the launch (the kernel returns them): the work DONE,
+                # not a nominal count -- the convergence test decides how many sweeps the algorithm needs
+                sw = float(sweeps_t.float().sum())
+                flops += sw * (n * (n - 1) / 2) * 14.0 * m
+                sweep_sum += sw
+                mats += b
                 tot_ms += ev_s.elapsed_time(ev_e)
                 launches += 1
             achieved = flops / (tot_ms / 1e3) / 1e12
@@ -212,8 +217,10 @@ def main():
                                     f"{probe_steps} instrumented eager steps of the same process before the timed region "
                                     "(the timed steps replay one hipGraph; device events cannot be recorded inside it; "
                                     "rocprofv3 of the same command sees the graph-launched kernels: profiles/)"),
+                    "mean_sweeps": sweep_sum / max(mats, 1),
                     "note": "VALU-issue-bound kernel priced against the fp32 vector = matrix peak; algorithmic flops = "
-                            "8 sweeps x n(n-1)/2 pairs x 14 m per matrix (DESIGN.md section 5)"}
+                            "sweeps actually run (returned per matrix by the kernel) x n(n-1)/2 pairs x 14 m "
+                            "(DESIGN.md section 5)"}
         vit_flops = global_batch * ((4 if args.grad_checkpointing else 3) * F_STUDENT + F_TEACHER)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
