@@ -439,3 +439,27 @@ def test_jacobi_block_ordering_large_batch(nat, m, n):
     aat = a[:16].double() @ a[:16].double().transpose(1, 2)
     assert torch.allclose(cols.transpose(1, 2) @ cols, aat, rtol=0, atol=2e-5 * float(aat.abs().max()))
     assert float(w[:, :, m:].abs().max()) == 0.0 if ld > m else True
+
+
+@pytest.mark.parametrize("batch", [4, 512])
+def test_jacobi_converges_on_clustered_spectra(nat, batch):
+    """groups of nearly equal singular values: tiny cosines still call for 45-degree rotations, so the
+    quadratic-convergence stop must not end the solve on the cosine alone (both the small-batch and the
+    block-ordering kernel)"""
+    n = 96
+    g = torch.Generator().manual_seed(7 + batch)
+    sv = torch.logspace(0, -2, n // 8, dtype=torch.float64).repeat_interleave(8)
+    sv = sv * (1 + 1e-6 * torch.randn(n, dtype=torch.float64, generator=g))
+    q1 = torch.linalg.qr(torch.randn(batch, n, n, dtype=torch.float64, generator=g))[0]
+    q2 = torch.linalg.qr(torch.randn(batch, n, n, dtype=torch.float64, generator=g))[0]
+    a = (q1 * sv) @ q2.transpose(1, 2)
+    w = _colmajor(a.float().cuda(), nat.jacobi_ld(n))
+    sigma, sweeps = nat.jacobi_svd(w, n)
+    cols = w[:4, :, :n].double()
+    gram = cols @ cols.transpose(1, 2)
+    d = torch.diagonal(gram, dim1=1, dim2=2).sqrt()
+    cos = (gram / (d.unsqueeze(2) * d.unsqueeze(1))).abs()
+    cos = cos - torch.diag_embed(torch.diagonal(cos, dim1=1, dim2=2))
+    assert float(cos.max()) < 3e-6, float(cos.max())
+    ref = torch.linalg.svdvals(a[:4])
+    assert torch.allclose(sigma[:4].cpu().double(), ref, rtol=2e-5, atol=0)

@@ -163,10 +163,15 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
 // interleave in each wave (ILP) and they share the barriers.  NMAT = 1 double-buffers the mailbox
 // (one barrier per step); NMAT = 2 uses one mailbox per matrix and two barriers per step.
 typedef float v4f __attribute__((ext_vector_type(4)));
-// Quadratic-convergence stop: a sweep whose largest rotated |cos| stayed below this leaves residual cosines of
-// its square (< 3e-7 < tol) -- the next sweep would only verify that.  Saves 1-2 of ~9 sweeps at n = 192 with
-// identical final orthogonality and singular values (numpy study over the odd-even ordering).
+// Quadratic-convergence stop: a sweep in which every rotation was SMALL -- |cos| of the pair below QUAD and
+// rotation tangent below QUAD_TAN -- is the last one: small-angle rotations at small cosines disturb the other
+// pairs of their columns by (sine x cosine) <= 5e-6 each, the residual cosines stay at the tolerance and the next
+// sweep would only verify that.  The tangent bound matters: inside a cluster of nearly equal singular values a
+// tiny cosine still calls for a 45-degree rotation, and stopping on the cosine alone leaves 1e-4 residuals there
+// (measured; scripts/time_jacobi.py has that stress case).  Saves 1-2 of ~9 sweeps at n = 192 on graded spectra
+// with identical final orthogonality and singular values.
 #define BASD_JACOBI_QUAD 5.0e-4f
+#define BASD_JACOBI_QUAD_TAN 1.0e-2f
 
 template <int MAXCH, int NMAT>
 __global__ __launch_bounds__(NMAT == 2 ? 768 : 1024)
@@ -258,9 +263,10 @@ __attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void 
           gamma = group8_sum(gamma);
           if (gamma * gamma > tol * tol * alpha * beta && gamma != 0.f) {
             rotated = true;
-            bigrot = bigrot || (gamma * gamma > BASD_JACOBI_QUAD * BASD_JACOBI_QUAD * alpha * beta);
+            const bool big_cos = gamma * gamma > BASD_JACOBI_QUAD * BASD_JACOBI_QUAD * alpha * beta;
             const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
             const float tt = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.f)));
+            bigrot = bigrot || big_cos || fabsf(tt) > BASD_JACOBI_QUAD_TAN;
             const float w1 = fmaf(tt, tt, 1.f);
             float c = __builtin_amdgcn_rsqf(w1);
             c = c * fmaf(-0.5f * w1, c * c, 1.5f);
@@ -481,9 +487,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float al = na, be = nb_;
     if (ok && g * g > tol2 * al * be && g != 0.f) {
       rotated = true;
-      bigrot = bigrot || (g * g > BASD_JACOBI_QUAD * BASD_JACOBI_QUAD * al * be);
+      const bool big_cos = g * g > BASD_JACOBI_QUAD * BASD_JACOBI_QUAD * al * be;
       const float z = (be - al) * __builtin_amdgcn_rcpf(2.f * g);
       const float t = copysignf(1.f, z) * __builtin_amdgcn_rcpf(fabsf(z) + __builtin_amdgcn_sqrtf(fmaf(z, z, 1.f)));
+      bigrot = bigrot || big_cos || fabsf(t) > BASD_JACOBI_QUAD_TAN;
       const float w = fmaf(t, t, 1.f);
       float c = __builtin_amdgcn_rsqf(w);
       c = c * fmaf(-0.5f * w, c * c, 1.5f);
