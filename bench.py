@@ -242,6 +242,7 @@ def main():
                          "tflops_if_whole_step": vit_flops / (ms_per_step / 1e3) / 1e12, "peak_bf16": 2500.0},
             "kernel_ms_per_step": {k: v["total_ms"] / probe_steps for k, v in ks.items()},
             "hip_graph": graphed, "hip_graph_error": trainer.graph_error,
+            "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 2**30,
             "host_enqueue_ms_per_step": 1e3 * host_s / args.steps,
             "loss": float(loss),
             "teacher_ranks": list(trainer.basd_loss.layer_selector.subspace_ranks.values()),
