@@ -463,3 +463,22 @@ def test_jacobi_converges_on_clustered_spectra(nat, batch):
     assert float(cos.max()) < 3e-6, float(cos.max())
     ref = torch.linalg.svdvals(a[:4])
     assert torch.allclose(sigma[:4].cpu().double(), ref, rtol=2e-5, atol=0)
+
+
+def test_empty_batches_are_noops(nat):
+    """zero-sized batches return without launching (every C-ABI entry checks for them first)"""
+    dev = "cuda"
+    ld = nat.jacobi_ld(32)
+    sigma, sweeps = nat.jacobi_svd(torch.zeros(0, 32, ld, device=dev), 32)
+    assert sigma.shape == (0, 32) and sweeps.shape == (0,)
+    w0, lwork, piv, rk = nat.pchol(torch.zeros(0, 32, 32, dtype=torch.float64, device=dev))
+    assert w0.shape[0] == 0 and rk.shape == (0,)
+    assert nat.trinv(lwork, piv, rk).shape == (0, 32, 32)
+    c = nat.bgemm_f64(torch.zeros(0, 64, 16, dtype=torch.float64, device=dev), torch.zeros(0, 16, 64, dtype=torch.float64, device=dev))
+    assert c.shape == (0, 64, 64)
+    y, mean, rstd = nat.layernorm_fwd(torch.zeros(0, 192, dtype=torch.bfloat16, device=dev), torch.ones(192, device=dev),
+                                      torch.zeros(192, device=dev), 1e-6)
+    assert y.shape == (0, 192) and mean.shape == (0,)
+    out, imp = nat.attention_fwd(torch.zeros(0, 197, 3 * 64, dtype=torch.bfloat16, device=dev), 1, 64, 0.125, True)
+    assert out.shape == (0, 197, 64) and imp.shape == (0, 196)
+    torch.cuda.synchronize()
