@@ -91,9 +91,12 @@ int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_b
  *        rows in ORIGINAL order (a[b] = W0 W0^T), columns >= rank zeroed;
  *   lwork[batch, n, n] fp64: the same columns in fp64 (column-major by step);
  *   piv  [batch, n] int32: pivot row chosen at step k (a permutation of 0..n-1);
- *   rank [batch] int32: number of pivots > tol * max diag.
+ *   rank [batch] int32: number of pivots > tol * dmax, dmax = the largest diagonal entry of a[b], or
+ *        dmax_ref[b] when dmax_ref (device fp64 [batch], nullable) is given: the panels of a BLOCKED
+ *        factorisation of a wider matrix stop relative to the diagonal of the whole matrix, not of their
+ *        own Schur complement.
  * Only the LOWER triangle of a[b] (row >= column) is read.  n <= 256. */
-int basd_pchol_f64(const double* a, int batch, int n, double tol,
+int basd_pchol_f64(const double* a, int batch, int n, double tol, const double* dmax_ref,
                    float* w0, int ld, double* lwork, int32_t* piv, int32_t* rank,
                    void* stream);
 
@@ -123,7 +126,7 @@ int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int nor
 
 /* Marchenko-Pastur rank on device (no host sync).  evals [batch, n] (any order),
  * rows = M of the [M, D] token matrix, d = D; uses the min(M, D) largest eigenvalues,
- * LOWER median, lambda_+ = med * (1 + sqrt(D/M))^2, count > lambda_+, clamp to cap. */
+ * LOWER median, lambda_+ = med * (1 + sqrt(D/M))^2, count > lambda_+, clamp to cap.  n <= 1024. */
 int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int cap,
                  int32_t* ranks, void* stream);
 

@@ -65,6 +65,17 @@ SHAPES = {
     # channels, uniform attention, resampled 49 -> 196 ("c3 degenerates, exactly")
     "c3_b4": Shape(B=4, N_s=196, N_t=49, D_s=192, D_t=2048, L_t=1, H=1, C=1000, has_cls=False,
                    r0=8, dr=4, decay=0.97),
+    # BASELINE config c2 at the BENCHMARKED batch (256 per GPU): pins the large-batch kernel variants
+    # (jacobi_blk, 1024-matrix pchol / trinv, aligned fp64 GEMM) against the reference itself
+    "c2_b256": Shape(B=256, N_s=196, N_t=196, D_s=192, D_t=768, L_t=12, H=12, C=1000,
+                     r0=8, dr=4, decay=0.97),
+    # BASELINE config c4 loss shapes at reduced batch: DeiT-S student (D_s = 384), ViT-L/16 teacher
+    "c4_b8": Shape(B=8, N_s=196, N_t=196, D_s=384, D_t=1024, L_t=24, H=16, C=1000,
+                   r0=8, dr=4, decay=0.985),
+    # BASELINE config c5 loss shapes at reduced batch: ViT-B student (D_s = 768), ViT-H/14 teacher
+    # (256 patch tokens, T = 257 -> resampled to 196)
+    "c5_b4": Shape(B=4, N_s=196, N_t=256, D_s=768, D_t=1280, L_t=32, H=16, C=1000,
+                   r0=8, dr=4, decay=0.99),
 }
 
 

@@ -31,41 +31,51 @@ def token_gram(x, proj, mirror=True):
     return g, z.sum(0)
 
 
-def pchol(a, tol=1e-13):
+def pchol(a, tol=1e-13, dmax_ref=None):
+    """Batched (vectorised over the batch) diagonal-pivoted Cholesky with the kernel's output contract."""
     a = a.double()
     a = torch.tril(a) + torch.tril(a, -1).transpose(-1, -2)     # only the lower triangle is read
     batch, n, _ = a.shape
     ld = jacobi_ld(n)
     lwork = torch.zeros(batch, n, n, dtype=torch.float64)
-    piv = torch.zeros(batch, n, dtype=torch.int32)
-    rank = torch.zeros(batch, dtype=torch.int32)
-    for b in range(batch):
-        d = torch.diagonal(a[b]).clone()
-        alive = torch.ones(n, dtype=torch.bool)
-        dmax0 = float(d.max())
-        k = 0
-        order = []
-        while k < n:
-            cand = torch.where(alive, d, torch.full_like(d, -1e300))
-            p = int(cand.argmax())
-            if not (float(cand[p]) > tol * dmax0) or not (float(cand[p]) > 0):
-                break
-            v = a[b, p] - lwork[b, :k].t() @ lwork[b, :k, p]
-            v = torch.where(alive, v, torch.zeros_like(v))
-            lkk = math.sqrt(max(float(v[p]), 0.0))
-            col = v / lkk
-            col[p] = lkk
-            lwork[b, k] = col
-            d = d - col * col
-            alive[p] = False
-            order.append(p)
-            k += 1
-        rank[b] = k
-        order += [i for i in range(n) if alive[i]]
-        piv[b] = torch.tensor(order, dtype=torch.int32)
+    piv = torch.zeros(batch, n, dtype=torch.long)
+    rank = torch.full((batch,), n, dtype=torch.long)
+    d = torch.diagonal(a, dim1=-2, dim2=-1).clone()
+    alive = torch.ones(batch, n, dtype=torch.bool)
+    running = torch.ones(batch, dtype=torch.bool)
+    dmax0 = d.max(dim=1).values if dmax_ref is None else dmax_ref.double().reshape(batch)
+    ar = torch.arange(batch)
+    for k in range(n):
+        cand = torch.where(alive, d, torch.full_like(d, -1e300))
+        pval, p = cand.max(dim=1)                                 # first index on ties, like the kernel
+        ok = running & (pval > tol * dmax0) & (pval > 0)
+        newly = running & ~ok
+        rank[newly] = k
+        running = ok
+        if not bool(running.any()):
+            break
+        row_p = a[ar, p]                                          # [batch, n] = A[p, :]
+        lp = lwork[ar, :, p]                                      # [batch, steps] = L[p, :k]
+        v = row_p - torch.einsum("bkr,bk->br", lwork, lp)
+        v = torch.where(alive, v, torch.zeros_like(v))
+        lkk = pval.clamp_min(0).sqrt()
+        col = v / lkk.clamp_min(1e-300).unsqueeze(1)
+        col[ar, p] = lkk
+        col = torch.where(running.unsqueeze(1), col, torch.zeros_like(col))
+        lwork[:, k] = col
+        d = torch.where(running.unsqueeze(1), d - col * col, d)
+        upd = alive.clone()
+        upd[ar, p] = False
+        alive = torch.where(running.unsqueeze(1), upd, alive)
+        piv[:, k] = torch.where(running, p, piv[:, k])
+    # complete the permutation with the rows never pivoted (ascending), per matrix
+    for b_ in range(batch):
+        r = int(rank[b_])
+        rest = torch.nonzero(alive[b_]).flatten()
+        piv[b_, r:] = rest[: n - r]
     w0 = torch.zeros(batch, n, ld, dtype=torch.float32)
     w0[:, :, :n] = lwork.float()
-    return w0, lwork, piv, rank
+    return w0, lwork, piv.int(), rank.int()
 
 
 def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True, active=None, active_rows=False):

@@ -32,10 +32,26 @@ def test_flat_tail_fixture_within_reference_noise_floor():
     check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-3)
 
 
-def test_rank_deficient_values():
+def test_rank_deficient_full_parity():
+    """N_s - 1 < D_s: token-side Procrustes; the gradients match the reference too (its arbitrary null-space
+    singular vectors are annihilated by the token matrices)."""
     shape, inputs, gold = load("tiny_rankdef")
     res = run_basd_loss(shape, inputs, gold, "hard")
-    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=1.0, check_grads=False)
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=2e-4)
+
+
+def test_c1_shapes_token_side_procrustes():
+    shape, inputs, gold = load("c1")
+    res = run_basd_loss(shape, inputs, gold, "hard")
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-4)
+
+
+def test_c4_shapes_blocked_eigensolver_host_logic():
+    """D_s = 384: blocked Cholesky panels, block-Jacobi tournament, Gram-form principal angles, token-side
+    Procrustes -- the orchestration in losses/functional.py, with the kernels emulated."""
+    shape, inputs, gold = load("c4_b8")
+    res = run_basd_loss(shape, inputs, gold, "hard")
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-4)
 
 
 def test_state_dict_keys_match_reference_surface():

@@ -39,20 +39,20 @@ def test_flat_tail():
     check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-3)
 
 
-def test_rank_deficient_values():
+def test_rank_deficient_full_parity():
+    # N_s - 1 < D_s: the cross-covariance is rank deficient.  The token-side Procrustes form (functional.
+    # _polar_token_side) never pairs null-space singular vectors, and the reference's arbitrary null-space part is
+    # annihilated by t_w / s_w in the gradient: gradients match, not only values.
     shape, inputs, gold = load("tiny_rankdef")
     res = run_basd_loss(shape, inputs, gold, "hard", device="cuda")
-    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=1.0, check_grads=False)
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=2e-4)
 
 
-def test_c1_shapes_values_and_grad_norms():
-    # c1: N_s - 1 = 63 < D_s = 192, the Procrustes cross-covariance is rank deficient: values,
-    # weights, ranks and the (well defined) logits / temperature grads are pinned; the student
-    # grads carry the reference's arbitrary null-space component and are compared by norm only.
+def test_c1_shapes_full_parity():
+    # BASELINE c1 loss shapes: N_s - 1 = 63 < D_s = 192 -> token-side Procrustes (64 x 64 cores)
     shape, inputs, gold = load("c1")
     res = run_basd_loss(shape, inputs, gold, "hard", device="cuda")
-    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=1.0, check_grads=False)
-    torch.testing.assert_close(res["grad_log_temperatures"], gold["hard/grad_log_temperatures"], atol=1e-7, rtol=5e-4)
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-4)
 
 
 def test_c2_shapes_full_parity():
@@ -62,6 +62,27 @@ def test_c2_shapes_full_parity():
     for l in inputs["token_layers"]:
         n_ref = float(gold[f"hard/grad_student_{l}_norm"])
         assert abs(float(res[f"grad_student_{l}"].double().norm()) - n_ref) <= 5e-4 * n_ref
+
+
+def _big_fixture(name, grad_tol=5e-4):
+    shape, inputs, gold = load(name)
+    res = run_basd_loss(shape, inputs, gold, "hard", device="cuda")
+    check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=grad_tol)
+    for l in inputs["token_layers"]:
+        n_ref = float(gold[f"hard/grad_student_{l}_norm"])
+        assert abs(float(res[f"grad_student_{l}"].double().norm()) - n_ref) <= 5e-4 * n_ref
+
+
+def test_c4_shapes_wide_student_parity():
+    """BASELINE c4 loss shapes (B reduced): DeiT-S student, D_s = 384 -> blocked Cholesky + block Jacobi for the
+    selector eigenproblems and principal angles, token-side Procrustes (D_t = 1024, L_t = 24)."""
+    _big_fixture("c4_b8")
+
+
+def test_c5_shapes_wide_student_parity():
+    """BASELINE c5 loss shapes (B reduced): ViT-B student, D_s = 768, ViT-H/14 teacher (D_t = 1280, L_t = 32,
+    256 -> 196 token resample)."""
+    _big_fixture("c5_b4")
 
 
 def test_c3_shapes_cnn_teacher_parity():

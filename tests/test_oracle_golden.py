@@ -69,7 +69,7 @@ def test_oracle_fp64_truth_agrees():
         assert rel_l2(res[f"grad_student_{l}"], gold[f"hard/grad_student_{l}"]) < 2e-4, l
 
 
-@pytest.mark.parametrize("name", ["c1", "c2_b8", "c3_b4"])
+@pytest.mark.parametrize("name", ["c1", "c2_b8", "c3_b4", "c4_b8", "c5_b4"])
 def test_oracle_matches_reference_baseline_shapes(name):
     shape, inputs, gold, res = _run(name, "hard")
     _check_values(gold, res, "hard")
@@ -78,6 +78,8 @@ def test_oracle_matches_reference_baseline_shapes(name):
         g = res[f"grad_student_{l}"]
         n_ref = float(gold[f"hard/grad_student_{l}_norm"])
         assert abs(float(g.double().norm()) - n_ref) <= 2e-4 * n_ref
-        if name in ("c2_b8", "c3_b4"):   # c1 is rank deficient in the Procrustes core (63 < 192)
+        if name != "c1":   # c1's committed per-sample slices predate the discovery below; norms are pinned
+            # (rank-deficient cores, N_s - 1 < D_s as in c4 / c5: the null-space part of U V^T is annihilated by
+            # the token matrices, so the gradients ARE well defined and compared in full)
             keep = gold[f"hard/grad_student_{l}"].shape[0]
             assert rel_l2(g[:keep], gold[f"hard/grad_student_{l}"]) < 5e-4, l

@@ -135,11 +135,34 @@ def _mirror_lower(gram: torch.Tensor) -> torch.Tensor:
     return low + torch.tril(gram, -1).t()
 
 
+def _split_rows(m: int) -> int:
+    """Number of K-slabs for the split-K Gram of a tall [m, d] matrix (slab rows stay a multiple of 4)."""
+    for s in (64, 32, 16, 8, 4, 2):
+        if m % (4 * s) == 0 and m // s >= 256:
+            return s
+    return 1
+
+
+def _token_gram_wide(x: torch.Tensor, proj: torch.Tensor):
+    """d_out > 256 (student widths 384 / 768, BASELINE c4 / c5): the fused one-pass kernel keeps a [128, d_out] z tile
+    and d_out^2 / 256 fp64 accumulator tiles on chip, which stops at 256 columns.  Here z = X P^T is materialised in
+    fp32 (plain library GEMM) and z^T z runs on the fp64 matrix cores as a split-K batched GEMM (basd_bgemm_f64,
+    symmetric tiles only) followed by the slab sum."""
+    z = torch.matmul(x.reshape(-1, x.shape[-1]).float(), proj.t())                 # [M, d_out] fp32
+    m, d = z.shape
+    s = _split_rows(m)
+    zs = z.view(s, m // s, d)
+    gram = bgemm_f64(zs, zs, trans_a=True, symmetric=True).sum(dim=0)              # [d, d] fp64
+    return gram, z.sum(dim=0, dtype=torch.float64)
+
+
 def token_gram(x: torch.Tensor, proj: torch.Tensor, mirror: bool = True):
     """x [M, d_in] or [B, N, d_in] view (f32/bf16), proj [d_out, d_in] f32 ->
     gram [d_out, d_out] f64, colsum [d_out] f64.  ``mirror=False`` leaves the strict upper triangle
     unspecified (the kernels fill lower tiles only; ``pchol`` reads nothing else)."""
     _need_cuda(x, proj)
+    if proj.shape[0] > 256 or proj.shape[0] % 16 or x.shape[-1] % 32:
+        return _token_gram_wide(x, proj.contiguous().float())
     x, m, d_in, rpb, bstride = _token_view(x)
     proj = proj.contiguous().float()
     d_out = proj.shape[0]
@@ -156,17 +179,22 @@ def token_gram(x: torch.Tensor, proj: torch.Tensor, mirror: bool = True):
     return (_mirror_lower(gram) if mirror else gram), colsum
 
 
-def pchol(a: torch.Tensor, tol: float = 1e-13):
-    """a [batch, n, n] f64 PSD -> (w0 [batch, n, ld] f32, lwork [batch, n, n] f64, piv, rank)."""
+def pchol(a: torch.Tensor, tol: float = 1e-13, dmax_ref: torch.Tensor | None = None):
+    """a [batch, n, n] f64 PSD -> (w0 [batch, n, ld] f32, lwork [batch, n, n] f64, piv, rank).
+    ``dmax_ref`` (fp64 [batch], optional): the stop test is ``pivot > tol * dmax_ref[b]`` instead of relative to the
+    matrix's own largest diagonal entry (panels of a blocked factorisation)."""
     _need_cuda(a)
     a = a.contiguous()
+    if dmax_ref is not None:
+        dmax_ref = dmax_ref.contiguous()
+        assert dmax_ref.dtype == torch.float64 and dmax_ref.numel() == a.shape[0]
     batch, n, _ = a.shape
     ld = jacobi_ld(n)
     w0 = torch.empty(batch, n, ld, dtype=torch.float32, device=a.device)
     lwork = torch.empty(batch, n, n, dtype=torch.float64, device=a.device)
     piv = torch.empty(batch, n, dtype=torch.int32, device=a.device)
     rank = torch.empty(batch, dtype=torch.int32, device=a.device)
-    _check(lib().basd_pchol_f64(_ptr(a), batch, n, ctypes.c_double(tol), _ptr(w0), ld, _ptr(lwork),
+    _check(lib().basd_pchol_f64(_ptr(a), batch, n, ctypes.c_double(tol), _ptr(dmax_ref), _ptr(w0), ld, _ptr(lwork),
                                 _ptr(piv), _ptr(rank), _stream()), "basd_pchol_f64")
     return w0, lwork, piv, rank
 

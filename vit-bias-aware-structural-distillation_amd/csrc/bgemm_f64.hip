@@ -247,8 +247,7 @@ extern "C" int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int 
   if (K <= 0 || batch > 65535) return fail(BASD_ERR_SHAPE, "bgemm_f64: bad shape batch=%d K=%d", batch, K);
   hipStream_t st = (hipStream_t)stream;
   const int key = a_dtype * 100 + b_dtype * 10 + c_dtype;
-  static const bool no_fast = getenv("BASD_BGEMM_PLAIN") != nullptr;   // debugging aid: element-wise staging only
-  const bool aligned = !no_fast && M % BT == 0 && N % BT == 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+  const bool aligned = M % BT == 0 && N % BT == 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
                        a_stride % 4 == 0 && b_stride % 4 == 0 && ((uintptr_t)a & 31) == 0 && ((uintptr_t)b & 31) == 0;
 #define BASD_BG(TA, TB, TC)                                                                                          \
   do {                                                                                                               \

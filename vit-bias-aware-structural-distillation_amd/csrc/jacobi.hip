@@ -695,8 +695,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
                        n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows); \
   } while (0)
-  static const bool column_ordering = getenv("BASD_JACOBI_COLUMNS") != nullptr;   // debugging aid: previous kernels
-  if (!column_ordering && active == nullptr && batch >= 512 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
+  if (active == nullptr && batch >= 512 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
     // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
     const int nbk = (n_cols + 1) / 2, slots = (nbk + 1) / 2;
     const int threads_b = ((slots * 8 + 63) / 64) * 64;

@@ -17,130 +17,6 @@
 
 namespace basd {
 
-__device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }
-
-// LDS-resident version: the lower triangle of A lives packed in LDS (fp64, n(n+1)/2 doubles,
-// 148 KiB at n = 192) and is overwritten column by column with the factor (left-looking, so
-// the slow LDS writes stay at n^2/2 while the reads are n^3/3).  Diagonal pivoting is done
-// with physical symmetric swaps inside the packed triangle; `perm` tracks original indices
-// and the outputs are scattered back to ORIGINAL row order at the end.
-// 768 threads = 192 rows x 4 j-slices.
-__global__ __launch_bounds__(768) void pchol_lds_kernel(const double* __restrict__ a_all, int n, double tol,
-                                                        float* __restrict__ w0_all, int ld,
-                                                        double* __restrict__ lw_all,
-                                                        int32_t* __restrict__ piv_all,
-                                                        int32_t* __restrict__ rank_all) {
-  extern __shared__ __align__(16) double X[];                 // packed lower triangle
-  const int tri_n = n * (n + 1) / 2;
-  double* s_d = X + tri_n;                                     // [n] residual diagonal
-  double* s_redv = s_d + n;                                    // [2][16] pivot candidates per wave (double buffered)
-  int* s_perm = reinterpret_cast<int*>(s_redv + 32);           // [n]
-  int* s_redi = s_perm + n;                                    // [2][16]
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const double* A = a_all + (size_t)blockIdx.x * n * n;
-  double* Lw = lw_all + (size_t)blockIdx.x * n * n;
-  float* W0 = w0_all + (size_t)blockIdx.x * n * ld;
-  int32_t* piv = piv_all + (size_t)blockIdx.x * n;
-
-  for (int e = tid; e < n * n; e += nt) {
-    const int i = e / n, j = e - i * n;
-    if (j <= i) X[tri(i, j)] = A[e];
-  }
-  for (int i = tid; i < n; i += nt) { s_d[i] = A[(size_t)i * n + i]; s_perm[i] = i; }
-  __syncthreads();
-  int rank = n;
-  const int row_l = tid >> 2, part = tid & 3;
-  const int nw = nt >> 6;
-  // Two barriers per step: (A) after the pivot candidates of every wave are in LDS -- each thread
-  // then reduces the <= 12 candidates itself and performs its share of the symmetric swap --
-  // (B) after the swap.  Column k is then formed, the residual diagonal updated and the NEXT
-  // step's pivot candidates reduced per wave before barrier (A) of the next step.  The pivot
-  // factor's diagonal entry is sqrt(pivot residual), which every thread already holds.
-  auto wave_argmax_to_lds = [&](double v, int idx, int slot) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ov = __shfl_xor(v, o, 64);
-      const int oi = __shfl_xor(idx, o, 64);
-      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-    if ((tid & 63) == 0) { s_redv[slot * 16 + (tid >> 6)] = v; s_redi[slot * 16 + (tid >> 6)] = idx; }
-  };
-  {
-    double v = -1.0e300; int idx = n;
-    for (int i = tid; i < n; i += nt) {
-      const double di = s_d[i];
-      if (di > v || (di == v && i < idx)) { v = di; idx = i; }
-    }
-    wave_argmax_to_lds(v, idx, 0);
-  }
-  double dmax0 = 0.0;
-  for (int k = 0; k < n; ++k) {
-    const int slot = k & 1;
-    __syncthreads();                                           // (A)
-    double pval = s_redv[slot * 16]; int p = s_redi[slot * 16];
-    for (int w = 1; w < nw; ++w) {
-      const double ov = s_redv[slot * 16 + w]; const int oi = s_redi[slot * 16 + w];
-      if (ov > pval || (ov == pval && oi < p)) { pval = ov; p = oi; }
-    }
-    if (k == 0) dmax0 = pval;
-    if (!(pval > tol * dmax0) || !(pval > 0.0)) { rank = k; break; }
-    // ---- symmetric swap of positions k and p inside the packed triangle
-    if (p != k) {
-      for (int e = tid; e < n; e += nt) {
-        if (e < k) {                         // row segments left of column k (already factor columns)
-          const double t = X[tri(k, e)]; X[tri(k, e)] = X[tri(p, e)]; X[tri(p, e)] = t;
-        } else if (e > k && e < p) {         // column k below the diagonal <-> row p
-          const double t = X[tri(e, k)]; X[tri(e, k)] = X[tri(p, e)]; X[tri(p, e)] = t;
-        } else if (e > p) {                  // columns k and p below row p
-          const double t = X[tri(e, k)]; X[tri(e, k)] = X[tri(e, p)]; X[tri(e, p)] = t;
-        } else if (e == k) {                 // diagonal entries, bookkeeping
-          const double t = X[tri(k, k)]; X[tri(k, k)] = X[tri(p, p)]; X[tri(p, p)] = t;
-          const double td = s_d[k]; s_d[k] = s_d[p]; s_d[p] = td;
-          const int tp = s_perm[k]; s_perm[k] = s_perm[p]; s_perm[p] = tp;
-        }
-      }
-    }
-    __syncthreads();                                           // (B)
-    // ---- column k: v_i = A[i,k] - sum_{j<k} L[i,j] L[k,j]   (i > k), 4 lanes per row.
-    //      l_kk = sqrt(residual diagonal of the pivot) is known to every thread (pval): nothing to
-    //      broadcast, and nobody reads X[k,k] while row k's group overwrites it.
-    const double lkk = sqrt(pval);
-    double dnew = -1.0e300;
-    const int i = k + row_l;
-    if (i < n) {
-      const double* xi = X + tri(i, 0);
-      const double* xk = X + tri(k, 0);
-      double acc = 0.0;
-      for (int j = part; j < k; j += 4) acc = fma(xi[j], xk[j], acc);
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      const double col = (i == k) ? lkk : (xi[k] - acc) / lkk;
-      if (i != k) dnew = s_d[i] - col * col;
-      if (part == 0) {
-        X[tri(i, k)] = col;
-        if (i != k) s_d[i] = dnew;
-      }
-    }
-    // next step's pivot candidates (positions > k): one value per row group, reduced per wave
-    wave_argmax_to_lds((part == 0 && i < n) ? dnew : -1.0e300, i, slot ^ 1);
-  }
-  __syncthreads();
-  // ---- scatter to the caller's layout (rows in ORIGINAL order, column-major by step)
-  for (int e = tid; e < n * n; e += nt) {
-    const int k = e / n, i = e - k * n;                       // step k, position i
-    const double v = (i >= k && k < rank) ? X[tri(i, k)] : 0.0;
-    const int r = s_perm[i];
-    Lw[(size_t)k * n + r] = v;
-    W0[(size_t)k * ld + r] = (float)v;
-  }
-  for (int e = tid; e < n * (ld - n); e += nt) {
-    const int k = e / (ld - n), r = n + (e - k * (ld - n));
-    W0[(size_t)k * ld + r] = 0.f;
-  }
-  for (int i = tid; i < n; i += nt) piv[i] = s_perm[i];
-  if (tid == 0) rank_all[blockIdx.x] = rank;
-}
-
 // Register-resident version (default for n <= 192): right-looking, the whole residual matrix
 // lives in VGPRs -- 768 threads as 24 x 32 tiles of 8 rows x 6 columns (48 doubles per thread) --
 // and LDS only carries the scaled pivot row (1.5 KiB) from its owners to everybody.
@@ -184,6 +60,7 @@ __device__ __forceinline__ void wave_argmax(double& v, int& idx) {
 }
 
 __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict__ a_all, int n, double tol,
+                                                        const double* __restrict__ dmax_ref,
                                                         float* __restrict__ w0_all, int ld,
                                                         double* __restrict__ lw_all,
                                                         int32_t* __restrict__ piv_all,
@@ -237,7 +114,7 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
     lds_barrier();                                              // (A) pivot visible, s_c free
     const double pval = s_pv;
     const int p = s_pi;
-    if (k == 0) dmax0 = pval;
+    if (k == 0) dmax0 = dmax_ref ? dmax_ref[blockIdx.x] : pval;
     if (!(pval > tol * dmax0) || !(pval > 0.0)) { rank = k; break; }
     if (tr == (p >> 3)) {                                       // owners of row p publish it
       const int pr = p & 7;
@@ -323,7 +200,8 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
 }
 
 __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ a_all, int n,
-                                                     double tol, float* __restrict__ w0_all, int ld,
+                                                     double tol, const double* __restrict__ dmax_ref,
+                                                     float* __restrict__ w0_all, int ld,
                                                      double* __restrict__ lw_all,
                                                      int32_t* __restrict__ piv_all,
                                                      int32_t* __restrict__ rank_all) {
@@ -369,7 +247,7 @@ __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ 
       double v = s_redv[0]; int idx = s_redi[0];
       for (int w = 1; w < 4; ++w)
         if (s_redv[w] > v || (s_redv[w] == v && s_redi[w] < idx)) { v = s_redv[w]; idx = s_redi[w]; }
-      if (k == 0) s_dmax0 = v;
+      if (k == 0) s_dmax0 = dmax_ref ? dmax_ref[blockIdx.x] : v;
       s_piv = idx; s_pivval = v;
     }
     __syncthreads();
@@ -419,15 +297,16 @@ __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ 
 }
 
 // Marchenko-Pastur rank, reference src/losses/layer_selector.py:8-20, on device.
-__global__ __launch_bounds__(256) void mp_rank_kernel(const float* __restrict__ evals, int n,
-                                                      float scale, int64_t rows, int d, int cap,
-                                                      int32_t* __restrict__ ranks) {
-  __shared__ float s_v[256];
-  __shared__ float s_sorted[256];
+__global__ __launch_bounds__(1024) void mp_rank_kernel(const float* __restrict__ evals, int n,
+                                                       float scale, int64_t rows, int d, int cap,
+                                                       int32_t* __restrict__ ranks) {
+  __shared__ float s_v[1024];
+  __shared__ float s_sorted[1024];
   __shared__ int s_count;
   const int tid = threadIdx.x;
   const float* e = evals + (size_t)blockIdx.x * n;
   s_v[tid] = (tid < n) ? e[tid] * scale : -1.f;
+  s_sorted[tid] = -1.f;
   if (tid == 0) s_count = 0;
   __syncthreads();
   if (tid < n) {
@@ -451,23 +330,17 @@ __global__ __launch_bounds__(256) void mp_rank_kernel(const float* __restrict__ 
 
 }  // namespace basd
 
-extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, float* w0, int ld,
+extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, const double* dmax_ref, float* w0, int ld,
                               double* lwork, int32_t* piv, int32_t* rank, void* stream) {
   using namespace basd;
   if (batch <= 0) return BASD_OK;
   if (n < 1 || n > 256 || ld < n || ld > 256 + 64)
     return fail(BASD_ERR_SHAPE, "pchol_f64: bad shape n=%d ld=%d", n, ld);
-  const size_t lds = ((size_t)n * (n + 1) / 2 + n + 32) * 8 + ((size_t)n + 32 + 2) * 4 + 64;
-  static const bool use_lds_kernel = getenv("BASD_PCHOL_LDS") != nullptr;   // debugging aid: previous kernel
-  if (n <= 192 && !use_lds_kernel) {
-    hipLaunchKernelGGL(pchol_reg_kernel, dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, w0, ld,
+  if (n <= 192) {
+    hipLaunchKernelGGL(pchol_reg_kernel, dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0, ld,
                        lwork, piv, rank);
-  } else if (lds <= 160 * 1024 && n <= 192) {
-    allow_full_lds((const void*)pchol_lds_kernel);
-    hipLaunchKernelGGL(pchol_lds_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, a, n, tol, w0, ld,
-                       lwork, piv, rank);
-  } else {   // global-memory (L2-resident) fallback for 192 < n <= 256
-    hipLaunchKernelGGL(pchol_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, a, n, tol, w0,
+  } else {   // global-memory (L2-resident) left-looking kernel for 192 < n <= 256
+    hipLaunchKernelGGL(pchol_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0,
                        ld, lwork, piv, rank);
   }
   return check_launch("pchol_f64");
@@ -477,9 +350,9 @@ extern "C" int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, 
                             int32_t* ranks, void* stream) {
   using namespace basd;
   if (batch <= 0) return BASD_OK;
-  if (n < 1 || n > 256 || rows < 1) return fail(BASD_ERR_SHAPE, "mp_rank: bad shape n=%d", n);
+  if (n < 1 || n > 1024 || rows < 1) return fail(BASD_ERR_SHAPE, "mp_rank: bad shape n=%d", n);
   // eigenvalues handed over are those of X^T X; the reference uses X^T X / M
-  hipLaunchKernelGGL(mp_rank_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, evals, n,
+  hipLaunchKernelGGL(mp_rank_kernel, dim3(batch), dim3(n <= 256 ? 256 : 1024), 0, (hipStream_t)stream, evals, n,
                      1.0f / (float)rows, rows, d, cap, ranks);
   return check_launch("mp_rank");
 }

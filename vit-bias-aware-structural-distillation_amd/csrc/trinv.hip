@@ -197,10 +197,9 @@ extern "C" int basd_trinv_f64(const double* lwork, const int32_t* piv, const int
   const size_t lds = (size_t)n * (n + 1) / 2 * 8 + (size_t)n * 4 + 64;
   if (n < 1 || lds > 160 * 1024)
     return fail(BASD_ERR_SHAPE, "trinv_f64: n=%d does not fit the LDS-resident packed triangle", n);
-  static const bool columnwise = getenv("BASD_TRINV_COLUMNWISE") != nullptr;   // debugging aid: previous kernel
   const int nb = (n + 15) / 16;
   const size_t lds_blk = (size_t)nb * (nb + 1) / 2 * 256 * 8 + (size_t)16 * nb * (8 + 4);
-  if (!columnwise && nb <= 12 && lds_blk <= 160 * 1024) {
+  if (nb <= 12 && lds_blk <= 160 * 1024) {
     allow_full_lds((const void*)trinv_blocked_kernel);
     hipLaunchKernelGGL(trinv_blocked_kernel, dim3(batch), dim3(768), lds_blk, (hipStream_t)stream, lwork, piv, rank, n,
                        out);

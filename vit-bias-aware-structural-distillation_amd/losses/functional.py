@@ -37,6 +37,88 @@ class BasdShapeError(NotImplementedError):
 # --------------------------------------------------------------------------- #
 # helpers
 # --------------------------------------------------------------------------- #
+WIDE_PANEL = 192          # widest eigenproblem of the LDS-resident Jacobi = panel of the blocked Cholesky
+WIDE_BLOCK = 96           # column block of the blocked Jacobi: a PAIR of blocks is one LDS-resident problem
+WIDE_SWEEPS = 5           # outer sweeps of the blocked Jacobi (fixed: no host sync; see tests for the margin)
+_ROUND_CACHE: dict = {}
+
+
+def _tournament(nblk: int, device):
+    """Round-robin schedule over ``nblk`` (even) column blocks: nblk - 1 rounds of nblk / 2 disjoint pairs, as
+    device index tensors [nblk] (pair p = entries 2p, 2p+1).  Cached: building them during a stream capture would be
+    an illegal host-to-device copy."""
+    key = (nblk, str(device))
+    hit = _ROUND_CACHE.get(key)
+    if hit is None:
+        ring = list(range(nblk))
+        rounds = []
+        for _ in range(nblk - 1):
+            pairs = []
+            for k in range(nblk // 2):
+                a, b = ring[k], ring[nblk - 1 - k]
+                pairs += [min(a, b), max(a, b)]
+            rounds.append(torch.tensor(pairs, dtype=torch.long, device=device))
+            ring = [ring[0]] + [ring[-1]] + ring[1:-1]
+        hit = _ROUND_CACHE[key] = rounds
+    return hit
+
+
+def _blocked_pchol(a64: torch.Tensor, n_pad: int) -> torch.Tensor:
+    """Blocked Cholesky of PSD fp64 matrices wider than one panel: A = X X^T with X returned in the Jacobi layout
+    [b, column (= elimination step), row] fp32.  Panels of WIDE_PANEL columns; inside a panel the register-resident
+    diagonal-pivoted kernel (basd_pchol_f64) factors the current Schur complement block -- pivoting is local to the
+    panel, the stop test is relative to the largest diagonal entry of the WHOLE matrix -- the rows below follow from
+    the explicit inverse of the panel factor (basd_trinv_f64) and the trailing update is one fp64 MFMA GEMM
+    (basd_bgemm_f64).  Only lower blocks of A are read."""
+    ops = get_ops()
+    b, n, _ = a64.shape
+    a = a64.new_zeros(b, n_pad, n_pad)
+    a[:, :n, :n] = a64
+    dref = a64.diagonal(dim1=-2, dim2=-1).amax(dim=-1).contiguous()
+    x = torch.zeros(b, n_pad, n_pad, dtype=torch.float32, device=a64.device)
+    for p0 in range(0, n_pad, WIDE_PANEL):
+        p1 = p0 + WIDE_PANEL
+        _, lw, piv, rank = ops.pchol(a[:, p0:p1, p0:p1].contiguous(), PCHOL_TOL, dmax_ref=dref)
+        x[:, p0:p1, p0:p1] = lw                                   # lw[b, step, row]: rows in original order
+        if p1 < n_pad:
+            l_inv = ops.trinv(lw, piv, rank)                      # [b, step, col] = L^-1 P (zero rows beyond the rank)
+            lb = ops.bgemm_f64(l_inv, a[:, p1:, p0:p1].contiguous(), trans_b=True)    # [b, step, rows below]
+            x[:, p0:p1, p1:] = lb
+            a[:, p1:, p1:] -= ops.bgemm_f64(lb, lb, trans_a=True)                     # Schur complement
+    return x
+
+
+def _psd_eig_blocked(a64: torch.Tensor):
+    """Eigen-decomposition of PSD fp64 matrices [b, n, n] with n > 192 (student widths 384 / 768: BASELINE c4 / c5).
+
+    One-sided BLOCK Jacobi on the blocked Cholesky factor X (A = X X^T): the columns form n_pad / 96 blocks; a round
+    of the tournament takes nblk / 2 disjoint block pairs of every matrix, and for each pair
+        G = Xp^T Xp (192 x 192, fp64 MFMA)  ->  psd_eig(G) = V  (pivoted Cholesky + LDS-resident Jacobi)
+        Xp <- Xp V                          (fp64-accumulated MFMA GEMM, stored fp32)
+    i.e. the 192-column pair is orthogonalised exactly and its rotation is applied as a GEMM.  Relative accuracy is
+    that of one-sided Jacobi (every update is a right-multiplication by a near-orthogonal matrix).  WIDE_SWEEPS outer
+    sweeps, no convergence test on the host.  Returns (sigma [b, n] descending, u [b, n, n] rows = eigenvectors)."""
+    ops = get_ops()
+    b, n, _ = a64.shape
+    n_pad = -(-n // WIDE_PANEL) * WIDE_PANEL
+    x = _blocked_pchol(a64, n_pad)                                       # [b, n_pad(col), n_pad(row)]
+    nblk = n_pad // WIDE_BLOCK
+    xv = x.view(b, nblk, WIDE_BLOCK, n_pad)
+    rounds = _tournament(nblk, x.device)
+    for _ in range(WIDE_SWEEPS):
+        for idx in rounds:
+            xp = xv[:, idx].reshape(b * (nblk // 2), 2 * WIDE_BLOCK, n_pad)
+            g = ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True)
+            _, v, _ = psd_eig(g)                                          # rows of v = eigenvectors of the pair Gram
+            xv[:, idx] = ops.bgemm_f64(v, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
+    nrm = x.double().square().sum(dim=-1).sqrt()                          # [b, n_pad] singular values = column norms
+    order = torch.argsort(nrm, dim=-1, descending=True, stable=True)[:, :n]
+    sigma = torch.gather(nrm, 1, order).float()
+    cols = torch.gather(x, 1, order.unsqueeze(-1).expand(b, n, n_pad))[:, :, :n]
+    u = torch.where(sigma.unsqueeze(-1) > 0, cols / sigma.clamp_min(1e-30).unsqueeze(-1), torch.zeros_like(cols))
+    return sigma, u
+
+
 def psd_eig(a64: torch.Tensor, lower_only: bool = False):
     """Batched eigen-decomposition of symmetric PSD fp64 matrices [b, n, n]
     (``lower_only``: only the lower triangles are meaningful, e.g. ``token_gram(..., mirror=False)``).
@@ -46,10 +128,9 @@ def psd_eig(a64: torch.Tensor, lower_only: bool = False):
     """
     ops = get_ops()
     n = a64.shape[-1]
-    if not ops.jacobi_fits(n, n):
-        raise BasdShapeError(
-            f"{n}x{n} eigenproblem does not fit the 160 KiB LDS-resident Jacobi (n <= ~200); "
-            "student widths above 192 are out of scope this round (DESIGN.md)")
+    if n > WIDE_PANEL:
+        sigma, u = _psd_eig_blocked(a64)
+        return sigma, u, None
     if not lower_only:
         a64 = 0.5 * (a64 + a64.transpose(-1, -2))
     w0, lwork, piv, rank = ops.pchol(a64, PCHOL_TOL)             # reads the lower triangle only
@@ -149,14 +230,21 @@ class _SelectorWeightsFn(torch.autograd.Function):
         a_full = torch.einsum("ibd,jcd->ijbc", v_s, vm_t)           # [E, L, D(b), D(c)]
         a_bar = a_full * keep.view(1, L, D, 1)                      # rows b < k_j
 
-        ld = ops.jacobi_ld(D)
-        w = torch.zeros(E * L, D, ld, device=dev, dtype=torch.float32)
-        w[:, :, :D] = a_bar.reshape(E * L, D, D).transpose(1, 2)    # column c contiguous
-        # only the leading k_j x k_j block of pair (i, j) is non-zero: sweep just that block
-        sig, _ = ops.jacobi_svd(w, D, active=ranks.repeat(E), active_rows=True)   # cosines, descending
-        sig = sig.view(E, L, D)
-        u_s = torch.where(sig.unsqueeze(-1) > 1e-20, w[:, :, :D].view(E, L, D, D) / sig.clamp_min(1e-20).unsqueeze(-1),
-                          torch.zeros(1, device=dev))               # [E, L, m, b]
+        if D <= WIDE_PANEL:
+            ld = ops.jacobi_ld(D)
+            w = torch.zeros(E * L, D, ld, device=dev, dtype=torch.float32)
+            w[:, :, :D] = a_bar.reshape(E * L, D, D).transpose(1, 2)    # column c contiguous
+            # only the leading k_j x k_j block of pair (i, j) is non-zero: sweep just that block
+            sig, _ = ops.jacobi_svd(w, D, active=ranks.repeat(E), active_rows=True)   # cosines, descending
+            sig = sig.view(E, L, D)
+            u_s = torch.where(sig.unsqueeze(-1) > 1e-20, w[:, :, :D].view(E, L, D, D) / sig.clamp_min(1e-20).unsqueeze(-1),
+                              torch.zeros(1, device=dev))               # [E, L, m, b]
+        else:
+            # wide students (D_s = 384 / 768): cosines and left singular vectors from the blocked eigen-solver on
+            # the fp64 Gram A_bar A_bar^T (zero rows / columns beyond k_j: the blocked Cholesky stops at the rank)
+            ab = a_bar.reshape(E * L, D, D)
+            sig, u_s, _ = psd_eig(ops.bgemm_f64(ab, ab, trans_b=True, symmetric=True))
+            sig, u_s = sig.view(E, L, D), u_s.view(E, L, D, D)
         sig_c = sig.clamp(max=1.0 - _EPS32)                         # layer_selector.py:100
         theta = torch.acos(sig_c)
         den = sw.sum(-1)                                            # [L]; 0 at rank 0 -> NaN like the reference
@@ -243,34 +331,63 @@ def mix_layers(w: torch.Tensor, layers) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # Procrustes
 # --------------------------------------------------------------------------- #
-def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
-    """nuclear norm [B] and polar factor G = U V^T [B, D_s, D_t] of cross = s_w^T t_w.
+def _polar_core(cross: torch.Tensor):
+    """cross [B, r, c] fp64 with r <= 196 -> (sigma [B, r] fp32, m [B, r, r] fp64) with polar(cross) = U V^T = m @ cross.
 
-    cross and its Gram are formed in fp64; the pivoted Cholesky factor L (cross = L Q2,
-    Q2 = L^-1 cross with orthonormal rows) is diagonalised by the fp32 Jacobi:
-    L J1 = U Sigma.  The right factor J1 = L^-1 (U Sigma) uses the explicit fp64 inverse of the graded L
-    (never from a division by sigma), so (U, J1) is a consistent pair and
-    G = U J1^T Q2 = (U J1^T L^-1) cross is orthonormal to working precision.
+    The Gram cross cross^T is formed in fp64; its pivoted Cholesky factor L (cross = L Q2, Q2 = L^-1 cross with
+    orthonormal rows) is diagonalised by the fp32 Jacobi: L J1 = U Sigma.  The right factor J1 = L^-1 (U Sigma) uses
+    the explicit fp64 inverse of the graded L (never a division by sigma), so (U, J1) is a consistent pair and
+    U V^T = U J1^T Q2 = (U J1^T L^-1) cross is orthonormal to working precision.
     """
     ops = get_ops()
-    d_s = s_w.shape[-1]
-    if not ops.jacobi_fits(d_s, d_s):
-        raise BasdShapeError(f"Procrustes core {d_s}x{d_s} does not fit the LDS-resident Jacobi")
-    cross = ops.bgemm_f64(s_w, t_w, trans_a=True)                       # [B, D_s, D_t] fp64
+    r = cross.shape[1]
     mx = ops.bgemm_f64(cross, cross, trans_b=True, symmetric=True)     # exactly symmetric by construction
     w0, lwork, piv, rank = ops.pchol(mx, PCHOL_TOL)
-    sigma, _ = ops.jacobi_svd(w0, d_s)                                  # w0[:, i, :d_s] = sigma_i u_i
+    sigma, _ = ops.jacobi_svd(w0, r)                                    # w0[:, i, :r] = sigma_i u_i
     l_inv = ops.trinv(lwork, piv, rank)                                 # L_p^-1 P  [B, k, r] fp64
-    wf = w0[:, :, :d_s].contiguous()                                    # [B, i, r] = sigma_i u_i[r]
+    wf = w0[:, :, :r].contiguous()                                      # [B, i, r] = sigma_i u_i[r]
     j1 = ops.bgemm_f64(l_inv, wf, trans_b=True)                         # [B, k, i]:  L J1 = U Sigma
     u = torch.where(sigma.unsqueeze(-1) > 0, wf / sigma.clamp_min(1e-30).unsqueeze(-1),
-                    torch.zeros(1, device=s_w.device))                  # [B, i, r]
+                    torch.zeros(1, device=cross.device))                # [B, i, r]
     theta = ops.bgemm_f64(u, j1, trans_a=True, trans_b=True)            # [B, r, k] = polar(L), fp64
-    # G = theta Q2 with Q2 = L^-1 cross (orthonormal rows): associate as (theta L^-1) cross so that the
-    # [k, D_t] factor is never rounded to fp32 and the fp32 library bmm disappears (all on the fp64 MFMA)
-    m = ops.bgemm_f64(theta, l_inv)                                     # [B, r, r'] fp64
-    g = ops.bgemm_f64(m, cross, out_dtype=torch.float32)                # [B, D_s, D_t]
-    return sigma.sum(dim=-1), g
+    # polar(cross) = theta Q2 with Q2 = L^-1 cross: associate as (theta L^-1) cross so that the [k, c] factor is
+    # never rounded to fp32 (all on the fp64 MFMA)
+    return sigma, ops.bgemm_f64(theta, l_inv)                           # [B, r, r'] fp64
+
+
+def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
+    """Feature-side form (D_s <= 192 <= N_s - 1, e.g. BASELINE c2): nuclear norm [B] and polar factor
+    G = U V^T [B, D_s, D_t] fp32 of cross = s_w^T t_w (formed in fp64)."""
+    ops = get_ops()
+    cross = ops.bgemm_f64(s_w, t_w, trans_a=True)                       # [B, D_s, D_t] fp64
+    sigma, m = _polar_core(cross)
+    return sigma.sum(dim=-1), ops.bgemm_f64(m, cross, out_dtype=torch.float32)
+
+
+def _polar_token_side(s_w: torch.Tensor, t_w: torch.Tensor):
+    """Token-side form for N_s <= D_s (every wide student: rank(cross) <= N_s - 1 = 195 for all BASELINE configs,
+    SURVEY section 7): nuclear norm [B] and the two N x N matrices of the backward,
+        t_w G^T = A_s s_w,   s_w G = A_t t_w      (G = U V^T of cross = s_w^T t_w, never formed).
+
+    With the pivoted Cholesky factors of the token Gram matrices, s_w s_w^T = R_s^T R_s and t_w t_w^T = R_t^T R_t
+    (R = the factor's columns, rows in original token order), s_w^T = Q_s R_s and t_w^T = Q_t R_t with orthonormal
+    Q = (W s_w)^T, W = L^-1 P.  Hence cross = Q_s (R_s R_t^T) Q_t^T: its singular values are those of the
+    rank x rank core C = R_s R_t^T, G = Q_s polar(C) Q_t^T, and
+        A_s = R_t^T polar(C)^T W_s,   A_t = R_s^T polar(C) W_t.
+    """
+    ops = get_ops()
+    gs = ops.bgemm_f64(s_w, s_w, trans_b=True, symmetric=True)          # [B, N, N] fp64
+    gt = ops.bgemm_f64(t_w, t_w, trans_b=True, symmetric=True)
+    _, r_s, piv_s, rk_s = ops.pchol(gs, PCHOL_TOL)                       # r_s[b, k, n] = R_s (zero rows beyond the rank)
+    _, r_t, piv_t, rk_t = ops.pchol(gt, PCHOL_TOL)
+    w_s = ops.trinv(r_s, piv_s, rk_s)                                    # [B, k, n]
+    w_t = ops.trinv(r_t, piv_t, rk_t)
+    core = ops.bgemm_f64(r_s, r_t, trans_b=True)                         # C [B, k_s, k_t] fp64
+    sigma, m = _polar_core(core)
+    pc = ops.bgemm_f64(m, core)                                          # polar(C) [B, k_s, k_t] fp64
+    a_s = ops.bgemm_f64(ops.bgemm_f64(pc, r_t), w_s, trans_a=True, out_dtype=torch.float32)    # (pc R_t)^T W_s
+    a_t = ops.bgemm_f64(ops.bgemm_f64(r_s, pc, trans_a=True), w_t, out_dtype=torch.float32)    # (R_s^T pc) W_t
+    return sigma.sum(dim=-1), a_s, a_t
 
 
 class _ProcrustesFn(torch.autograd.Function):
@@ -291,23 +408,34 @@ class _ProcrustesFn(torch.autograd.Function):
         for i in range(E):
             sl = slice(i * b, (i + 1) * b)
             ops.procrustes_prep(students[i], t_all[i], imp_all[i], out=(s_w[sl], t_w[sl], a[sl], tr[sl]))
-        nuc, g = _polar_of_cross(s_w, t_w)
-        ctx.save_for_backward(s_w, t_w, a, g, imp_all)
+        ctx.token_side = n_s <= d_s
+        if not ops.jacobi_fits(min(n_s, d_s), min(n_s, d_s)):
+            raise BasdShapeError(f"Procrustes core min(N_s, D_s) = {min(n_s, d_s)} does not fit the LDS-resident Jacobi")
+        if ctx.token_side:
+            nuc, a_s, a_t = _polar_token_side(s_w, t_w)
+            ctx.save_for_backward(s_w, t_w, a, imp_all, a_s, a_t)
+        else:
+            nuc, g = _polar_of_cross(s_w, t_w)
+            ctx.save_for_backward(s_w, t_w, a, imp_all, g)
         ctx.n_t, ctx.E = n_t, E
         ctx.s_dtype = students[0].dtype
         return (tr[:, 0] + tr[:, 1] - 2.0 * nuc).view(E, -1)
 
     @staticmethod
     def backward(ctx, g_loss):
-        s_w, t_w, a, g, imp_all = ctx.saved_tensors
+        s_w, t_w, a, imp_all, *polar = ctx.saved_tensors
         E = ctx.E
         n_s, n_t = s_w.shape[1], ctx.n_t
         ops = get_ops()
         gl = g_loss.float().reshape(-1).contiguous()
         # residuals R = W - (other side) G^T, their scaling by 2 gl sqrt(a) and the row dots <R, W> that
         # make up d loss / d a: one fused pass per side over the GEMM result
-        g_s, dot_s = ops.procrustes_bwd_rows(t_w @ g.transpose(1, 2), s_w, a, gl, out_dtype=ctx.s_dtype)
-        g_t, dot_t = ops.procrustes_bwd_rows(s_w @ g, t_w, a, gl, out_dtype=torch.float32)
+        if ctx.token_side:
+            p_s, p_t = polar[0] @ s_w, polar[1] @ t_w                # t_w G^T = A_s s_w, s_w G = A_t t_w
+        else:
+            p_s, p_t = t_w @ polar[0].transpose(1, 2), s_w @ polar[0]
+        g_s, dot_s = ops.procrustes_bwd_rows(p_s, s_w, a, gl, out_dtype=ctx.s_dtype)
+        g_t, dot_t = ops.procrustes_bwd_rows(p_t, t_w, a, gl, out_dtype=torch.float32)
         g_a = (dot_s + dot_t) / (2.0 * a)
         imp = imp_all.float().reshape(-1, n_t)
         if n_t != n_s:
