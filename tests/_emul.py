@@ -9,6 +9,10 @@ import math
 import torch
 
 JACOBI_LDS_BYTES = 163840
+# Emulated rounding of the fp32 Jacobi: the real kernel stops at pair cosines of ~1e-6, so its singular vectors are
+# orthonormal to ~1e-6 only (absolute).  Host logic that is sensitive to this (the blocked eigensolver applies them to
+# graded factors) is tested with this switched on.
+JACOBI_NOISE = 0.0
 
 
 def jacobi_ld(m_rows: int) -> int:
@@ -91,6 +95,10 @@ def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True,
         out = torch.zeros(m_rows, n_cols, dtype=torch.float64)
         small = s < 1e-13 * max(float(s[0]), 1e-300)
         s = torch.where(small, torch.zeros_like(s), s)
+        if JACOBI_NOISE:
+            gen = torch.Generator().manual_seed(b)
+            u = u + JACOBI_NOISE * torch.randn(u.shape, generator=gen, dtype=torch.float64)
+            u = u / u.norm(dim=0, keepdim=True)
         out[:norm_rows, :r] = u * s
         if m_rows > norm_rows:                          # stacked [A; B]: B V
             out[norm_rows:, :r] = full[norm_rows:] @ vh.t()

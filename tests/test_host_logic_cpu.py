@@ -50,7 +50,13 @@ def test_c4_shapes_blocked_eigensolver_host_logic():
     """D_s = 384: blocked Cholesky panels, block-Jacobi tournament, Gram-form principal angles, token-side
     Procrustes -- the orchestration in losses/functional.py, with the kernels emulated."""
     shape, inputs, gold = load("c4_b8")
-    res = run_basd_loss(shape, inputs, gold, "hard")
+    # emulate the fp32 Jacobi's 1e-6 orthogonality error: without the fp64 refinement of the pair rotations the
+    # blocked eigensolver loses the small end of the graded spectrum (student gradient off by 1e-2 on the GPU)
+    _emul.JACOBI_NOISE = 1e-6
+    try:
+        res = run_basd_loss(shape, inputs, gold, "hard")
+    finally:
+        _emul.JACOBI_NOISE = 0.0
     check_against_golden(gold, res, "hard", inputs["token_layers"], grad_tol=5e-4)
 
 

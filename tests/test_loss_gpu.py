@@ -73,6 +73,12 @@ def _big_fixture(name, grad_tol=5e-4):
         assert abs(float(res[f"grad_student_{l}"].double().norm()) - n_ref) <= 5e-4 * n_ref
 
 
+def test_c2_bench_batch_parity():
+    """BASELINE c2 at the BENCHMARKED per-GPU batch (256): E*B = 1024 Procrustes cores -> jacobi_blk_kernel, the
+    1024-matrix pchol_reg / trinv_blocked launches and the aligned fp64 GEMM, all against the reference itself."""
+    _big_fixture("c2_b256")
+
+
 def test_c4_shapes_wide_student_parity():
     """BASELINE c4 loss shapes (B reduced): DeiT-S student, D_s = 384 -> blocked Cholesky + block Jacobi for the
     selector eigenproblems and principal angles, token-side Procrustes (D_t = 1024, L_t = 24)."""

@@ -39,7 +39,9 @@ class BasdShapeError(NotImplementedError):
 # --------------------------------------------------------------------------- #
 WIDE_PANEL = 192          # widest eigenproblem of the LDS-resident Jacobi = panel of the blocked Cholesky
 WIDE_BLOCK = 96           # column block of the blocked Jacobi: a PAIR of blocks is one LDS-resident problem
-WIDE_SWEEPS = 5           # outer sweeps of the blocked Jacobi (fixed: no host sync; see tests for the margin)
+WIDE_SWEEPS = 4           # outer sweeps of the blocked Jacobi (fixed: no host sync; converged after 3 on c4 / c5 shapes)
+WIDE_REFINE_STEPS = 1     # fp64 refinement steps of the full eigenvector matrix afterwards (_refine_eigenvectors)
+WIDE_CLUSTER_REL = 1e-3   # eigenvalue pairs closer than this (relative) are refined as a cluster
 _ROUND_CACHE: dict = {}
 
 
@@ -110,13 +112,57 @@ def _psd_eig_blocked(a64: torch.Tensor):
             xp = xv[:, idx].reshape(b * (nblk // 2), 2 * WIDE_BLOCK, n_pad)
             g = ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True)
             _, v, _ = psd_eig(g)                                          # rows of v = eigenvectors of the pair Gram
+            # v is orthonormal to ~1e-6 (fp32 Jacobi); applied to a graded pair that would leave column cosines of
+            # 1e-6 x sigma_i / sigma_j: one fp64 refinement step against g first (well inside its basin here)
+            _, v = _refine_eigenvectors(g, v.double(), steps=1)
             xv[:, idx] = ops.bgemm_f64(v, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
     nrm = x.double().square().sum(dim=-1).sqrt()                          # [b, n_pad] singular values = column norms
     order = torch.argsort(nrm, dim=-1, descending=True, stable=True)[:, :n]
-    sigma = torch.gather(nrm, 1, order).float()
-    cols = torch.gather(x, 1, order.unsqueeze(-1).expand(b, n, n_pad))[:, :, :n]
-    u = torch.where(sigma.unsqueeze(-1) > 0, cols / sigma.clamp_min(1e-30).unsqueeze(-1), torch.zeros_like(cols))
-    return sigma, u
+    sig0 = torch.gather(nrm, 1, order)
+    cols = torch.gather(x, 1, order.unsqueeze(-1).expand(b, n, n_pad))[:, :, :n].double()
+    u0 = torch.where(sig0.unsqueeze(-1) > 0, cols / sig0.clamp_min(1e-300).unsqueeze(-1), torch.zeros_like(cols))
+    lam, u = _refine_eigenvectors(a64, u0)
+    order = torch.argsort(lam, dim=-1, descending=True, stable=True)
+    lam = torch.gather(lam, 1, order)
+    u = torch.gather(u, 1, order.unsqueeze(-1).expand(b, n, n))
+    return lam.clamp_min(0).sqrt().float(), u.float()
+
+
+def _refine_eigenvectors(a64: torch.Tensor, u: torch.Tensor, steps: int = WIDE_REFINE_STEPS):
+    """Iterative refinement of an approximate eigen-decomposition in fp64 (Ogita & Aishima 2018, Algorithm 1, with a
+    RELATIVE cluster test so that graded spectra are refined too); every product on the fp64 matrix cores.
+
+    a64 [b, n, n] symmetric PSD (lower triangle meaningful), u [b, n, n] fp64 with ROWS the approximate unit
+    eigenvectors (zero rows = directions dropped at the numerical rank; they stay zero).  With X = u^T:
+        R = I - X^T X,  S = X^T A X,  lam_i = S_ii / (1 - R_ii),
+        E_ij = (S_ij + lam_j R_ij) / (lam_j - lam_i)   for well separated (i, j),   R_ij / 2 otherwise,
+        X <- X + X E.
+    Why it is needed: the pair rotations of the block Jacobi are applied as GEMMs with eigenvectors that are
+    orthonormal to 1e-6 only (fp32 Jacobi); on a graded factor that leaves cosines of 1e-6 x sigma_i / sigma_j
+    between the transformed columns (measured 2.5e-4 at D_s = 384, a 1e-2 error in the student gradient).  The
+    refinement is quadratically convergent from there: two steps reach fp64 rounding for separated eigenvalues,
+    and clusters keep their (accurate) invariant subspace and are re-orthonormalised.
+    Returns (lam [b, n] fp64 Rayleigh quotients of the LAST evaluation, u refined)."""
+    ops = get_ops()
+    b, n, _ = a64.shape
+    a = torch.tril(a64) + torch.tril(a64, -1).transpose(-1, -2)           # the producers fill lower triangles only
+    eye = torch.eye(n, dtype=torch.float64, device=a64.device)
+    lam = None
+    for _ in range(steps):
+        live = (u.abs().amax(dim=-1) > 0)                                  # [b, n]
+        pair_live = live.unsqueeze(1) & live.unsqueeze(2)
+        r = eye - ops.bgemm_f64(u, u, trans_b=True, symmetric=True)       # I - X^T X (rows of u are the columns of X)
+        s = ops.bgemm_f64(ops.bgemm_f64(u, a), u, trans_b=True)           # X^T A X
+        r_d = torch.diagonal(r, dim1=-2, dim2=-1)
+        lam = torch.where(live, torch.diagonal(s, dim1=-2, dim2=-1) / (1.0 - torch.where(live, r_d, torch.zeros_like(r_d))),
+                          torch.zeros_like(r_d))
+        li, lj = lam.unsqueeze(2), lam.unsqueeze(1)                        # E[i, j]: i = row index
+        gap = lj - li
+        sep = gap.abs() > WIDE_CLUSTER_REL * torch.maximum(li.abs(), lj.abs())
+        e = torch.where(sep, (s + lj * r) / torch.where(sep, gap, torch.ones_like(gap)), 0.5 * r)
+        e = torch.where(pair_live, e, torch.zeros_like(e))
+        u = u + ops.bgemm_f64(e, u, trans_a=True)                          # rows: u_j += sum_i E_ij u_i
+    return lam, u
 
 
 def psd_eig(a64: torch.Tensor, lower_only: bool = False):
