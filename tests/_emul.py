@@ -10,7 +10,7 @@ import torch
 
 JACOBI_LDS_BYTES = 163840
 # Emulated rounding of the fp32 Jacobi: the real kernel stops at pair cosines of ~1e-6, so its singular vectors are
-# orthonormal to ~1e-6 only (absolute).  Host logic that is sensitive to this (the blocked eigensolver applies them to
+# orthonormal to ~1e-6 only (absolute; JACOBI_NOISE is per ENTRY, 1e-7 gives that level at n = 192).  Host logic that is sensitive to this (the blocked eigensolver applies them to
 # graded factors) is tested with this switched on.
 JACOBI_NOISE = 0.0
 

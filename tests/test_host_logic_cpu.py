@@ -52,7 +52,7 @@ def test_c4_shapes_blocked_eigensolver_host_logic():
     shape, inputs, gold = load("c4_b8")
     # emulate the fp32 Jacobi's 1e-6 orthogonality error: without the fp64 refinement of the pair rotations the
     # blocked eigensolver loses the small end of the graded spectrum (student gradient off by 1e-2 on the GPU)
-    _emul.JACOBI_NOISE = 1e-6
+    _emul.JACOBI_NOISE = 1e-7      # per entry of a 192-vector: pair cosines of ~1.4e-6, the kernel's level
     try:
         res = run_basd_loss(shape, inputs, gold, "hard")
     finally:

@@ -39,10 +39,14 @@ class BasdShapeError(NotImplementedError):
 # --------------------------------------------------------------------------- #
 WIDE_PANEL = 192          # widest eigenproblem of the LDS-resident Jacobi = panel of the blocked Cholesky
 WIDE_BLOCK = 96           # column block of the blocked Jacobi: a PAIR of blocks is one LDS-resident problem
-WIDE_SWEEPS = 4           # outer sweeps of the blocked Jacobi (fixed: no host sync; converged after 3 on c4 / c5 shapes)
-WIDE_REFINE_STEPS = 1     # fp64 refinement steps of the full eigenvector matrix afterwards (_refine_eigenvectors)
-WIDE_CLUSTER_REL = 1e-3   # eigenvalue pairs closer than this (relative) are refined as a cluster
 _ROUND_CACHE: dict = {}
+
+
+def _wide_sweeps(nblk: int) -> int:
+    """Outer sweeps of the blocked Jacobi: fixed per width (no host sync).  Measured on graded random-basis spectra
+    (condition 1e3 .. 4e3, emulated fp32-Jacobi rounding): column cosines reach their floor after 3 sweeps at 4 blocks
+    (D_s = 384) and after 6 at 8 blocks (D_s = 768); one sweep of margin."""
+    return 3 + (nblk + 1) // 2 if nblk > 4 else 4
 
 
 def _tournament(nblk: int, device):
@@ -95,11 +99,11 @@ def _psd_eig_blocked(a64: torch.Tensor):
 
     One-sided BLOCK Jacobi on the blocked Cholesky factor X (A = X X^T): the columns form n_pad / 96 blocks; a round
     of the tournament takes nblk / 2 disjoint block pairs of every matrix, and for each pair
-        G = Xp^T Xp (192 x 192, fp64 MFMA)  ->  psd_eig(G) = V  (pivoted Cholesky + LDS-resident Jacobi)
-        Xp <- Xp V                          (fp64-accumulated MFMA GEMM, stored fp32)
-    i.e. the 192-column pair is orthogonalised exactly and its rotation is applied as a GEMM.  Relative accuracy is
-    that of one-sided Jacobi (every update is a right-multiplication by a near-orthogonal matrix).  WIDE_SWEEPS outer
-    sweeps, no convergence test on the host.  Returns (sigma [b, n] descending, u [b, n, n] rows = eigenvectors)."""
+        G = Xp^T Xp (192 x 192, fp64 MFMA)  ->  J = _pair_rotation(G)  (pivoted Cholesky + LDS-resident Jacobi)
+        Xp <- Xp J                          (fp64-accumulated MFMA GEMM, stored fp32)
+    i.e. the 192-column pair is orthogonalised completely and its rotation is applied as a GEMM; the accuracy is that
+    of one-sided Jacobi (relative per column).  The number of outer sweeps is fixed per width (_wide_sweeps): there is
+    no convergence test on the host.  Returns (sigma [b, n] descending, u [b, n, n] rows = eigenvectors)."""
     ops = get_ops()
     b, n, _ = a64.shape
     n_pad = -(-n // WIDE_PANEL) * WIDE_PANEL
@@ -107,62 +111,42 @@ def _psd_eig_blocked(a64: torch.Tensor):
     nblk = n_pad // WIDE_BLOCK
     xv = x.view(b, nblk, WIDE_BLOCK, n_pad)
     rounds = _tournament(nblk, x.device)
-    for _ in range(WIDE_SWEEPS):
+    for _ in range(_wide_sweeps(nblk)):
         for idx in rounds:
             xp = xv[:, idx].reshape(b * (nblk // 2), 2 * WIDE_BLOCK, n_pad)
-            g = ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True)
-            _, v, _ = psd_eig(g)                                          # rows of v = eigenvectors of the pair Gram
-            # v is orthonormal to ~1e-6 (fp32 Jacobi); applied to a graded pair that would leave column cosines of
-            # 1e-6 x sigma_i / sigma_j: one fp64 refinement step against g first (well inside its basin here)
-            _, v = _refine_eigenvectors(g, v.double(), steps=1)
-            xv[:, idx] = ops.bgemm_f64(v, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
+            rot = _pair_rotation(ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True))
+            xv[:, idx] = ops.bgemm_f64(rot, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
     nrm = x.double().square().sum(dim=-1).sqrt()                          # [b, n_pad] singular values = column norms
     order = torch.argsort(nrm, dim=-1, descending=True, stable=True)[:, :n]
-    sig0 = torch.gather(nrm, 1, order)
-    cols = torch.gather(x, 1, order.unsqueeze(-1).expand(b, n, n_pad))[:, :, :n].double()
-    u0 = torch.where(sig0.unsqueeze(-1) > 0, cols / sig0.clamp_min(1e-300).unsqueeze(-1), torch.zeros_like(cols))
-    lam, u = _refine_eigenvectors(a64, u0)
-    order = torch.argsort(lam, dim=-1, descending=True, stable=True)
-    lam = torch.gather(lam, 1, order)
-    u = torch.gather(u, 1, order.unsqueeze(-1).expand(b, n, n))
-    return lam.clamp_min(0).sqrt().float(), u.float()
+    sigma = torch.gather(nrm, 1, order).float()
+    cols = torch.gather(x, 1, order.unsqueeze(-1).expand(b, n, n_pad))[:, :, :n]
+    u = torch.where(sigma.unsqueeze(-1) > 0, cols / sigma.clamp_min(1e-30).unsqueeze(-1), torch.zeros_like(cols))
+    return sigma, u
 
 
-def _refine_eigenvectors(a64: torch.Tensor, u: torch.Tensor, steps: int = WIDE_REFINE_STEPS):
-    """Iterative refinement of an approximate eigen-decomposition in fp64 (Ogita & Aishima 2018, Algorithm 1, with a
-    RELATIVE cluster test so that graded spectra are refined too); every product on the fp64 matrix cores.
+def _pair_rotation(g: torch.Tensor) -> torch.Tensor:
+    """g = Xp^T Xp [b, k, k] fp64 (Gram of a column-block pair) -> J^T [b, k, k] fp64: row i holds the coefficients of
+    output column i over the input columns; Xp J has mutually orthogonal columns sorted by norm, J is orthogonal.
 
-    a64 [b, n, n] symmetric PSD (lower triangle meaningful), u [b, n, n] fp64 with ROWS the approximate unit
-    eigenvectors (zero rows = directions dropped at the numerical rank; they stay zero).  With X = u^T:
-        R = I - X^T X,  S = X^T A X,  lam_i = S_ii / (1 - R_ii),
-        E_ij = (S_ij + lam_j R_ij) / (lam_j - lam_i)   for well separated (i, j),   R_ij / 2 otherwise,
-        X <- X + X E.
-    Why it is needed: the pair rotations of the block Jacobi are applied as GEMMs with eigenvectors that are
-    orthonormal to 1e-6 only (fp32 Jacobi); on a graded factor that leaves cosines of 1e-6 x sigma_i / sigma_j
-    between the transformed columns (measured 2.5e-4 at D_s = 384, a 1e-2 error in the student gradient).  The
-    refinement is quadratically convergent from there: two steps reach fp64 rounding for separated eigenvalues,
-    and clusters keep their (accurate) invariant subspace and are re-orthonormalised.
-    Returns (lam [b, n] fp64 Rayleigh quotients of the LAST evaluation, u refined)."""
+    J has to be accurate in the GRADED sense (a big column may leak into a small one only by tol x sigma_small /
+    sigma_big), which the normalised left vectors U of the LDS Jacobi are not: they are orthonormal to 1e-6 in
+    absolute terms, and Xp U then has column cosines of 1e-6 x sigma_big / sigma_small (measured on the GPU: 2.5e-4 at
+    D_s = 384, a 1e-2 error of the student gradient; an fp64 Newton refinement of U diverges once that product
+    approaches 1).  Instead, with the pivoted Cholesky factor g = L L^T, the Jacobi orthogonalises the columns of
+    F = L^T (F^T F = g, so its RIGHT singular vectors are the eigenvectors of g): F J = W, and J = L^-T W with the
+    explicit fp64 inverse.  Then Xp J = (Xp L^-T) W = Q W with Q orthonormal: every output column inherits exactly the
+    relative rounding of its own W column and cos(x'_i, x'_j) = cos(w_i, w_j) <= the Jacobi tolerance, for any grading.
+    Output columns beyond the numerical rank of the pair (cancellation noise of dependent columns) are zeroed."""
     ops = get_ops()
-    b, n, _ = a64.shape
-    a = torch.tril(a64) + torch.tril(a64, -1).transpose(-1, -2)           # the producers fill lower triangles only
-    eye = torch.eye(n, dtype=torch.float64, device=a64.device)
-    lam = None
-    for _ in range(steps):
-        live = (u.abs().amax(dim=-1) > 0)                                  # [b, n]
-        pair_live = live.unsqueeze(1) & live.unsqueeze(2)
-        r = eye - ops.bgemm_f64(u, u, trans_b=True, symmetric=True)       # I - X^T X (rows of u are the columns of X)
-        s = ops.bgemm_f64(ops.bgemm_f64(u, a), u, trans_b=True)           # X^T A X
-        r_d = torch.diagonal(r, dim1=-2, dim2=-1)
-        lam = torch.where(live, torch.diagonal(s, dim1=-2, dim2=-1) / (1.0 - torch.where(live, r_d, torch.zeros_like(r_d))),
-                          torch.zeros_like(r_d))
-        li, lj = lam.unsqueeze(2), lam.unsqueeze(1)                        # E[i, j]: i = row index
-        gap = lj - li
-        sep = gap.abs() > WIDE_CLUSTER_REL * torch.maximum(li.abs(), lj.abs())
-        e = torch.where(sep, (s + lj * r) / torch.where(sep, gap, torch.ones_like(gap)), 0.5 * r)
-        e = torch.where(pair_live, e, torch.zeros_like(e))
-        u = u + ops.bgemm_f64(e, u, trans_a=True)                          # rows: u_j += sum_i E_ij u_i
-    return lam, u
+    b, k, _ = g.shape
+    _, lw, piv, rank = ops.pchol(g, PCHOL_TOL)                             # lw[b, step, row] = L[row, step]
+    wf = torch.zeros(b, k, ops.jacobi_ld(k), dtype=torch.float32, device=g.device)
+    wf[:, :, :k] = lw.transpose(1, 2)                                      # column r of F = row r of L (entries over steps)
+    ops.jacobi_svd(wf, k)                                                  # F J = W in place, columns sorted by norm
+    l_inv = ops.trinv(lw, piv, rank)                                       # [b, step, row] = L^-1 (rows >= rank zero)
+    rot = ops.bgemm_f64(wf[:, :, :k].contiguous(), l_inv)                  # J^T[i, r] = sum_step W[i, step] L^-1[step, r]
+    keep = torch.arange(k, device=g.device).unsqueeze(0) < rank.unsqueeze(1)
+    return rot * keep.unsqueeze(-1)
 
 
 def psd_eig(a64: torch.Tensor, lower_only: bool = False):
