@@ -52,6 +52,14 @@ extern "C" {
 #define BASD_ERR_WORKSPACE 3    /* workspace too small                           */
 #define BASD_ERR_DTYPE 4        /* unsupported dtype code                        */
 
+/* Device-side health flags: kernels whose failure is data dependent OR them (atomically) into an optional
+ * caller-owned int32 word instead of returning them -- no entry ever synchronises with the device.  The host
+ * side reads the word when it chooses to (the Python binding: once per step, one step late, and raises a
+ * torch.linalg.LinAlgError, which is what the reference's torch.linalg calls raise on such input). */
+#define BASD_STATUS_NONCONVERGED 1   /* a Jacobi solve used all max_sweeps sweeps and was still rotating      */
+#define BASD_STATUS_NONFINITE 2      /* NaN / Inf among the singular values (non-finite input)               */
+#define BASD_STATUS_RANK0 4          /* Marchenko-Pastur rank 0: the reference divides by sum(sw) = 0 here   */
+
 #define BASD_DTYPE_F32 0
 #define BASD_DTYPE_BF16 1
 #define BASD_DTYPE_F64 2
@@ -118,17 +126,19 @@ int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank,
  * active (optional, device int32 [batch], may be NULL): matrix b has non-zero entries only in its
  * leading active[b] columns (and rows, if active_rows != 0); the sweeps then run over that
  * block only (rank-masked principal-angle problems, no host sync on the ranks).
+ * status (optional, device int32 word, may be NULL): BASD_STATUS_NONCONVERGED / BASD_STATUS_NONFINITE are OR-ed in.
  * Requires n_cols <= 256, ld % 4 == 0, n_cols * ld * 4 + 4096 <= 160 KiB. */
 int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
                     float tol, int max_sweeps, int sort,
                     float* sigma, int32_t* sweeps, const int32_t* active, int active_rows,
-                    void* stream);
+                    int32_t* status, void* stream);
 
 /* Marchenko-Pastur rank on device (no host sync).  evals [batch, n] (any order),
  * rows = M of the [M, D] token matrix, d = D; uses the min(M, D) largest eigenvalues,
- * LOWER median, lambda_+ = med * (1 + sqrt(D/M))^2, count > lambda_+, clamp to cap.  n <= 1024. */
+ * LOWER median, lambda_+ = med * (1 + sqrt(D/M))^2, count > lambda_+, clamp to cap.  n <= 1024.
+ * status (optional device int32 word): BASD_STATUS_RANK0 when a count is 0, BASD_STATUS_NONFINITE for a NaN spectrum. */
 int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int cap,
-                 int32_t* ranks, void* stream);
+                 int32_t* ranks, int32_t* status, void* stream);
 
 /* mixed[i] = sum_j w[i, j] * x_j   (all E mixes from ONE pass over the teacher layers)
  * x_layers: HOST array of L device pointers to [elems] tensors (dtype code; the pointers are

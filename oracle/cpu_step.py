@@ -17,6 +17,40 @@ import time
 import torch
 
 
+def reference_loss_backward(s_model, t_model, x_clean, x_aug, targets, *, proj_s, proj_t, log_temperatures, layers,
+                            smoothing):
+    """One forward + backward of the BASD step in plain torch on whatever device / dtype the models live on (CPU fp32
+    for the checker): frozen teacher with per-block token capture and FULL attention-map capture (the reference's
+    hooks, src/models/teacher.py:27-39,180-216), student with token taps (src/training/trainer.py:16-37), the oracle
+    loss.  Leaves ``.grad`` on the student parameters and ``log_temperatures``; returns the oracle's output dict."""
+    from oracle import basd_oracle as O
+    t_tok, t_att, hooks = {}, {}, []
+    for i, blk in enumerate(t_model.blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: t_tok.__setitem__(i, o[:, 1:])))
+
+        def attn_hook(m, a, o, i=i):
+            xin = a[0]
+            b, n, c = xin.shape
+            qkv = m.qkv(xin).reshape(b, n, 3, m.num_heads, c // m.num_heads).permute(2, 0, 3, 1, 4)
+            t_att[i] = ((qkv[0] @ qkv[1].transpose(-2, -1)) * m.scale).softmax(-1)
+        hooks.append(blk.attn.register_forward_hook(attn_hook))
+    with torch.no_grad():
+        t_model(x_clean)
+    for h in hooks:
+        h.remove()
+    s_tok, hooks = {}, []
+    for l in layers:
+        hooks.append(s_model.blocks[l].register_forward_hook(lambda m, a, o, l=l: s_tok.__setitem__(l, o[:, 1:])))
+    logits = s_model(x_aug)
+    for h in hooks:
+        h.remove()
+    out = O.basd_loss(logits, targets, s_tok, t_tok, t_att, layers=layers, proj_s=proj_s, proj_t=proj_t,
+                      log_temperatures=log_temperatures, has_cls=True, smoothing=smoothing)
+    out["loss"].backward()
+    out["logits"] = logits.detach()
+    return out
+
+
 def cpu_step_images_per_sec(*, student="deit_tiny_patch16_224", teacher="vit_base_patch16_224", img=224,
                             batch=8, num_classes=1000, timed_steps=2, warmup=1, seed=0):
     from basd_amd.models.vit import create_vit
@@ -50,29 +84,8 @@ def cpu_step_images_per_sec(*, student="deit_tiny_patch16_224", teacher="vit_bas
     labels = torch.randint(0, num_classes, (batch,))
 
     def step(k):
-        t_tok, t_att, hooks = {}, {}, []
-        for i, blk in enumerate(t_model.blocks):
-            hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: t_tok.__setitem__(i, o[:, 1:])))
-
-            def attn_hook(m, a, o, i=i):
-                xin = a[0]
-                b, n, c = xin.shape
-                qkv = m.qkv(xin).reshape(b, n, 3, m.num_heads, c // m.num_heads).permute(2, 0, 3, 1, 4)
-                t_att[i] = ((qkv[0] @ qkv[1].transpose(-2, -1)) * m.scale).softmax(-1)
-            hooks.append(blk.attn.register_forward_hook(attn_hook))
-        with torch.no_grad():
-            t_model(x)
-        for h in hooks:
-            h.remove()
-        s_tok, hooks = {}, []
-        for l in layers:
-            hooks.append(s_model.blocks[l].register_forward_hook(lambda m, a, o, l=l: s_tok.__setitem__(l, o[:, 1:])))
-        logits = s_model(x)
-        for h in hooks:
-            h.remove()
-        out = O.basd_loss(logits, labels, s_tok, t_tok, t_att, layers=layers, proj_s=proj_s, proj_t=proj_t,
-                          log_temperatures=log_t, has_cls=True, smoothing=1.0 / num_classes)
-        out["loss"].backward()
+        out = reference_loss_backward(s_model, t_model, x, x, labels, proj_s=proj_s, proj_t=proj_t,
+                                      log_temperatures=log_t, layers=layers, smoothing=1.0 / num_classes)
         lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-8, 0.05
         ckp1 = 1.0 / (k + 1)
         bc2 = 1 - b2 ** (k + 1)

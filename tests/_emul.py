@@ -15,6 +15,28 @@ JACOBI_LDS_BYTES = 163840
 JACOBI_NOISE = 0.0
 
 
+def handles(t) -> bool:
+    return True
+
+
+_STATUS = torch.zeros(1, dtype=torch.int32)
+
+
+def status_word(device=None):
+    return _STATUS
+
+
+def raise_for_status(value):
+    from basd_amd._native import raise_for_status as real
+    real(value)
+
+
+def check_status(device=None):
+    value = int(_STATUS[0])
+    _STATUS.zero_()
+    raise_for_status(value)
+
+
 def jacobi_ld(m_rows: int) -> int:
     ld = (m_rows + 3) // 4 * 4
     if ld % 32 == 0:
@@ -87,6 +109,11 @@ def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True,
     if norm_rows is None:
         norm_rows = m_rows
     sigma = torch.zeros(batch, n_cols, dtype=torch.float32)
+    if not bool(torch.isfinite(w).all()):
+        _STATUS[0] |= 2
+        w.copy_(torch.nan_to_num(w, nan=0.0, posinf=0.0, neginf=0.0))
+        sigma.fill_(float("nan"))
+        return sigma, torch.full((batch,), 1, dtype=torch.int32)
     for b in range(batch):
         full = w[b, :, :m_rows].double().t()           # [m, n]
         top = full[:norm_rows]
@@ -118,6 +145,8 @@ def mp_rank(evals, rows, d, cap):
         sigma2 = asc[(n_eff - 1) // 2]
         edge = float(sigma2.float()) * (1.0 + math.sqrt(d / rows)) ** 2
         out.append(min(int((srt.float() > edge).sum()), cap))
+        if out[-1] == 0:
+            _STATUS[0] |= 4 if math.isfinite(edge) else 2
     return torch.tensor(out, dtype=torch.int32)
 
 

@@ -189,6 +189,104 @@ def test_bgemm_f64(nat, ta, tb, dt_a, dt_b, dt_c):
     assert torch.allclose(c.cpu().double(), ref, rtol=0, atol=tol * float(ref.abs().max()) * K ** 0.5)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("dt_a,dt_b,dt_c", [(torch.float32, torch.float32, torch.float64),
+                                            (torch.float32, torch.float32, torch.float32),
+                                            (torch.float64, torch.float64, torch.float64),
+                                            (torch.float64, torch.float64, torch.float32),
+                                            (torch.float64, torch.float32, torch.float64),
+                                            (torch.float64, torch.float32, torch.float32),
+                                            (torch.float32, torch.float64, torch.float64),
+                                            (torch.float32, torch.float64, torch.float32)])
+def test_bgemm_f64_aligned_fast_kernel(nat, ta, tb, dt_a, dt_b, dt_c):
+    """64-aligned shapes dispatch bgemm_f64_fast_kernel (register prefetch, double-buffered LDS): the kernel the
+    benchmark's Procrustes chain runs -- every dtype combination and transpose against fp64 torch"""
+    g = torch.Generator().manual_seed(17)
+    batch, M, N, K = 5, 192, 256, 196
+    a = torch.randn(batch, *((K, M) if ta else (M, K)), generator=g, dtype=torch.float64).to(dt_a)
+    b = torch.randn(batch, *((N, K) if tb else (K, N)), generator=g, dtype=torch.float64).to(dt_b)
+    c = nat.bgemm_f64(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb, out_dtype=dt_c)
+    ref = (a.double().transpose(1, 2) if ta else a.double()) @ (b.double().transpose(1, 2) if tb else b.double())
+    tol = 1e-12 if dt_c == torch.float64 else 1e-6
+    assert c.dtype == dt_c
+    assert torch.allclose(c.cpu().double(), ref, rtol=0, atol=tol * float(ref.abs().max()) * K ** 0.5)
+
+
+def test_bgemm_f64_aligned_symmetric_and_split_k(nat):
+    """symmetric tile skipping on aligned shapes + the split-K Gram of the wide token statistics (_token_gram_wide)"""
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(4, 192, 320, generator=g, dtype=torch.float64)
+    c = nat.bgemm_f64(x.cuda(), x.cuda(), trans_b=True, symmetric=True).cpu()
+    ref = x @ x.transpose(1, 2)
+    assert torch.allclose(c, ref, rtol=0, atol=1e-12 * float(ref.abs().max()))
+    assert torch.equal(c, c.transpose(1, 2))
+    tok = torch.randn(2048, 256, generator=g)
+    proj = torch.randn(384, 256, generator=g) / 16
+    gram, colsum = nat.token_gram(tok.cuda(), proj.cuda())
+    z = (tok @ proj.t()).double()
+    assert torch.allclose(gram.cpu(), z.t() @ z, rtol=0, atol=2e-6 * float((z.t() @ z).abs().max()))
+    assert torch.allclose(colsum.cpu(), z.sum(0), rtol=0, atol=1e-4 * float(z.sum(0).abs().max()))
+
+
+@pytest.mark.parametrize("n,decay", [(384, 0.985), (768, 0.99), (384, 0.97)])
+def test_blocked_eigensolver_graded_spectra(nat, n, decay):
+    """psd_eig for n > 192 (blocked Cholesky + block Jacobi with right-vector pair rotations) on random-basis graded
+    spectra up to condition 1e5 in sigma: eigenvalues RELATIVE 2e-5 over the whole spectrum, orthonormal vectors,
+    small residual.  A left-vector (U) pair rotation fails this at 2.5e-4 .. divergence."""
+    from basd_amd.losses import functional as BF, _ops
+    _ops.set_ops(None)
+    g = torch.Generator().manual_seed(n)
+    q, _ = torch.linalg.qr(torch.randn(2, n, n, generator=g, dtype=torch.float64))
+    sig = decay ** torch.arange(n, dtype=torch.float64)
+    a = ((q * sig ** 2) @ q.transpose(1, 2)).cuda()
+    s, u, _ = BF.psd_eig(a)
+    nat.check_status()
+    assert float(((s.double().cpu() - sig) / sig).abs().max()) < 2e-5
+    ud = u.double()
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    assert float((ud @ ud.transpose(1, 2) - eye).abs().max()) < 5e-6
+    res = ud @ a - (s.double() ** 2).unsqueeze(-1) * ud
+    assert float((res.norm(dim=-1) / (s.double() ** 2)).max()) < 1e-3      # relative to EACH eigenvalue
+
+
+def test_blocked_eigensolver_rank_deficient(nat):
+    """rank 150 in 384 dimensions: the blocked Cholesky stops at the rank, null directions come back as zero rows"""
+    from basd_amd.losses import functional as BF, _ops
+    _ops.set_ops(None)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, 600, 150, generator=g, dtype=torch.float64) @ torch.randn(2, 150, 384, generator=g, dtype=torch.float64)
+    a = (z.transpose(1, 2) @ z).cuda()
+    s, u, _ = BF.psd_eig(a)
+    ref = torch.linalg.svdvals(z)
+    assert torch.allclose(s[:, :150].double().cpu(), ref[:, :150], rtol=1e-5, atol=0)
+    assert float(s[:, 150:].abs().max()) <= 1e-6 * float(ref.max())
+    live = u.abs().amax(-1) > 0
+    assert live.sum(1).tolist() == [150, 150]
+
+
+def test_status_word_flags_nonfinite_nonconverged_and_rank0(nat):
+    """data-dependent failures are OR-ed into the device health word and surface as a LinAlgError on check"""
+    nat.check_status()                                        # clean slate
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(4, 48, 32, generator=g).cuda()
+    w = _colmajor(a, nat.jacobi_ld(48))
+    nat.jacobi_svd(w.clone(), 48)
+    nat.check_status()                                        # healthy input: no flag
+    bad = w.clone()
+    bad[1, 3, 5] = float("nan")
+    nat.jacobi_svd(bad, 48)
+    with pytest.raises(torch.linalg.LinAlgError, match="non-finite"):
+        nat.check_status()
+    nat.check_status()                                        # cleared by the failed check
+    nat.jacobi_svd(w.clone(), 48, max_sweeps=1)
+    with pytest.raises(torch.linalg.LinAlgError, match="without converging"):
+        nat.check_status()
+    ev = torch.ones(3, 64, device="cuda")                     # flat spectrum: nothing above the MP edge
+    assert nat.mp_rank(ev, 4096, 64, 63).tolist() == [0, 0, 0]
+    with pytest.raises(torch.linalg.LinAlgError, match="rank 0"):
+        nat.check_status()
+
+
 @pytest.mark.parametrize("n,rank", [(32, 32), (32, 20), (192, 192), (192, 100)])
 def test_trinv_matches_triangular_solve(nat, n, rank):
     g = torch.Generator().manual_seed(n * 7 + rank)

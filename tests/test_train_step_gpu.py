@@ -41,6 +41,69 @@ def test_graph_replay_matches_eager():
     assert graphed.optimizer.k == 3
 
 
+def test_c1_step_matches_the_cpu_oracle_step():
+    """One BASELINE-c1-size step (DeiT-T / ViT-S, 32x32, patch 4) on the HIP path against the CPU restatement of the
+    whole step (oracle/cpu_step.py: plain fp32 torch ViTs + the oracle loss pinned to the reference) on IDENTICAL
+    weights, projections and images: ranks exact, mixing weights, loss terms, and the gradient of every student
+    parameter.  The GPU path runs bf16 activations (the CPU one fp32), which sets the tolerances: loss terms 1 %,
+    flat gradient: norm within 3 %, cosine > 0.995."""
+    from basd_amd.models.vit import create_vit
+    from oracle.cpu_step import reference_loss_backward
+    trainer, batch = _make(32)
+    teacher = trainer._teacher
+    sel = trainer.basd_loss.layer_selector
+    with torch.no_grad():
+        sel.log_temperatures.add_(torch.linspace(-0.3, 0.3, 4, device="cuda"))
+    # ---- CPU copies (fp32) of exactly the weights the GPU path uses
+    s_cpu = create_vit("deit_tiny_patch16_224", num_classes=100, img_size=32, patch_size=4).train()
+    s_cpu.load_state_dict({k: v.detach().float().cpu() for k, v in trainer.model.state_dict().items()})
+    t_cpu = create_vit("vit_small_patch16_224", num_classes=0, img_size=32, patch_size=4).eval()
+    t_cpu.load_state_dict({k: v.detach().float().cpu() for k, v in teacher.model.state_dict().items()})
+    log_t = sel.log_temperatures.detach().cpu().clone().requires_grad_(True)
+    targets = batch["label"].cpu()
+    want = reference_loss_backward(s_cpu, t_cpu, batch["clean"].cpu(), batch["augmented"].cpu(), targets,
+                                   proj_s=sel.proj_s.cpu(), proj_t=sel.proj_t.cpu(), log_temperatures=log_t,
+                                   layers=trainer.basd_loss.token_layers, smoothing=trainer.criterion.label_smoothing)
+    # ---- HIP path: forward + backward of the train step (no optimizer update: gradients are compared)
+    loss, logits = trainer._forward_backward(batch["clean"], batch["augmented"], batch["label"])
+    torch.cuda.synchronize()
+    from basd_amd.losses._ops import get_ops
+    get_ops().check_status()
+    # bf16 tokens on one side, fp32 on the other: with a random-init teacher on noise images the MP threshold sits
+    # inside the dense noise bulk (ranks ~70 of 192), so a rank may move by one or two across the two precisions
+    assert max(abs(a - b) for a, b in zip(sel.subspace_ranks.values(), want["ranks"].tolist())) <= 2
+    torch.testing.assert_close(sel.last_weights.cpu(), want["weights"].detach(), atol=5e-3, rtol=0)
+    torch.testing.assert_close(trainer.basd_loss.last_terms["geo"].cpu(), want["geo"].detach(), rtol=1e-2, atol=0)
+    torch.testing.assert_close(trainer.basd_loss.last_terms["ce"].cpu(), want["ce"].detach(), rtol=1e-2, atol=0)
+    torch.testing.assert_close(loss.cpu(), want["loss"].detach(), rtol=1e-2, atol=0)
+    got, ref = [], []
+    cpu_params = dict(s_cpu.named_parameters())
+    for name, p in trainer.model.named_parameters():
+        got.append(p.grad.detach().float().cpu().flatten())
+        ref.append(cpu_params[name].grad.flatten())
+    got, ref = torch.cat(got), torch.cat(ref)
+    cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
+    print(f"step-level: loss {float(loss):.5f} vs {float(want['loss']):.5f}; |g| {float(got.norm()):.4e} vs "
+          f"{float(ref.norm()):.4e}; cosine {cos:.5f}")
+    assert abs(float(got.norm()) - float(ref.norm())) <= 3e-2 * float(ref.norm())
+    assert cos > 0.995
+    g_t = sel.log_temperatures.grad.detach().cpu()
+    torch.testing.assert_close(g_t, log_t.grad, rtol=5e-2, atol=1e-6)
+
+
+def test_non_finite_input_raises_a_linalg_error_one_step_late():
+    """a NaN image poisons the tokens: the Jacobi / MP-rank kernels flag it in the device health word and the trainer
+    raises when the next step starts (no host sync inside a step; the reference raises from inside torch.linalg)"""
+    trainer, batch = _make(16)
+    trainer.train_step(batch)
+    bad = dict(batch)
+    bad["clean"] = batch["clean"].clone()
+    bad["clean"][3, 1, 5, 7] = float("nan")
+    trainer.train_step(bad)                      # flags are set by this step's kernels ...
+    with pytest.raises(torch.linalg.LinAlgError):
+        trainer.train_step(batch)                # ... and looked at when the next one starts
+
+
 def test_eager_step_is_deterministic_up_to_atomics():
     a, batch = _make(16)
     b, _ = _make(16)

@@ -26,8 +26,48 @@ EXPORTS = (
 )
 
 
+_P, _I, _I64, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+# argument types of every export, in the order of include/basd_hip.h
+_SIGNATURES = {
+    "basd_version": (),
+    "basd_last_error": (),
+    "basd_token_gram": (_P, _I, _I64, _I, _I, _I64, _P, _I, _P, _P, _P),
+    "basd_token_gram_bf16x3": (_P, _I64, _I, _I, _I64, _P, _I, _P, _P, _P),
+    "basd_pchol_f64": (_P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P),
+    "basd_trinv_f64": (_P, _P, _P, _I, _I, _P, _P),
+    "basd_jacobi_svd": (_P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _I, _P, _P),
+    "basd_mp_rank": (_P, _I, _I, _I64, _I, _I, _P, _P, _P),
+    "basd_mix_tokens": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
+    "basd_procrustes_prep": (_P, _I, _I64, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P),
+    "basd_mix_grad_dots": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
+    "basd_bgemm_f64": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P),
+    "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
+    "basd_layernorm_fwd_bf16": (_P, _P, _P, _I64, _I, _F, _P, _P, _P, _P),
+    "basd_add_layernorm_fwd_bf16": (_P, _P, _P, _P, _I64, _I, _F, _P, _P, _P, _P, _P),
+    "basd_layernorm_bwd_bf16": (_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P),
+    "basd_procrustes_bwd_rows": (_P, _P, _P, _P, _I64, _I, _I, _P, _I, _P, _P),
+    "basd_cls_importance_bf16": (_P, _I, _I, _I, _I, _F, _P, _P),
+    "basd_attention_fwd_bf16": (_P, _I, _I, _I, _I, _F, _P, _P, _P),
+    "basd_sf_adamw_step": (_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _D, _D, _P),
+    "basd_lerp": (_P, _P, _I64, _F, _P),
+}
+
+
 class BasdNativeError(RuntimeError):
     pass
+
+
+class BasdLinAlgError(torch.linalg.LinAlgError):
+    """Data-dependent failure of a linear-algebra kernel (non-finite input, Jacobi without convergence, a rank-0
+    teacher layer): the counterpart of the ``torch._C._LinAlgError`` the reference's ``torch.linalg`` calls raise."""
+
+
+STATUS_NONCONVERGED, STATUS_NONFINITE, STATUS_RANK0 = 1, 2, 4
+_STATUS_TEXT = {
+    STATUS_NONCONVERGED: "a Jacobi SVD used all its sweeps without converging",
+    STATUS_NONFINITE: "non-finite values reached a Jacobi SVD / the Marchenko-Pastur rank (NaN or Inf in the tokens)",
+    STATUS_RANK0: "a teacher layer has Marchenko-Pastur rank 0 (pure-noise tokens): the reference's weights are NaN here",
+}
 
 
 def build(verbose: bool = False) -> str:
@@ -51,10 +91,12 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the BASD kernels)")
         L = ctypes.CDLL(LIB_PATH)
-        L.basd_last_error.restype = ctypes.c_char_p
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise BasdNativeError(f"{LIB_PATH} does not export {name}")
+            fn = getattr(L, name)
+            fn.argtypes = list(_SIGNATURES[name])      # explicit: no default int conversion of 64-bit sizes / pointers
+            fn.restype = ctypes.c_char_p if name == "basd_last_error" else ctypes.c_int
         _lib = L
     return _lib
 
@@ -81,10 +123,44 @@ def _dtype_code(t: torch.Tensor) -> int:
     raise BasdNativeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
 
 
+def handles(t: torch.Tensor) -> bool:
+    """The kernels of this provider take device tensors only (module code asks before choosing the fused path)."""
+    return t.is_cuda
+
+
 def _need_cuda(*ts: torch.Tensor) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
             raise BasdNativeError("BASD kernels need tensors on an MI355X device (no CPU path)")
+
+
+_STATUS: dict = {}
+
+
+def status_word(device) -> torch.Tensor:
+    """The per-device int32 health word the data-dependent kernels OR their flags into (allocated once; kernels
+    captured in a hipGraph keep writing to it)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    buf = _STATUS.get(key)
+    if buf is None:
+        buf = _STATUS[key] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+    return buf
+
+
+def raise_for_status(value: int) -> None:
+    if value:
+        what = "; ".join(text for bit, text in _STATUS_TEXT.items() if value & bit)
+        raise BasdLinAlgError(f"BASD kernels reported status {value}: {what}")
+
+
+def check_status(device=None) -> None:
+    """Read (synchronising) and clear the health word of ``device``; raises BasdLinAlgError if a kernel flagged a
+    failure since the last check."""
+    buf = status_word(device if device is not None else torch.cuda.current_device())
+    value = int(buf.item())
+    if value:
+        buf.zero_()
+    raise_for_status(value)
 
 
 def jacobi_ld(m_rows: int) -> int:
@@ -218,7 +294,7 @@ def jacobi_svd(w: torch.Tensor, m_rows: int, norm_rows: int | None = None, *, to
     _check(lib().basd_jacobi_svd(_ptr(w), batch, m_rows, n_cols, ld, norm_rows, ctypes.c_float(tol),
                                  max_sweeps, int(sort), _ptr(sigma), _ptr(sweeps),
                                  _ptr(None if active is None else active.contiguous().int()), int(active_rows),
-                                 _stream()),
+                                 _ptr(status_word(w.device)), _stream()),
            "basd_jacobi_svd")
     return sigma, sweeps
 
@@ -233,8 +309,8 @@ def mp_rank(evals: torch.Tensor, rows: int, d: int, cap: int) -> torch.Tensor:
     evals = evals.contiguous().float()
     batch, n = evals.shape
     ranks = torch.empty(batch, dtype=torch.int32, device=evals.device)
-    _check(lib().basd_mp_rank(_ptr(evals), batch, n, ctypes.c_int64(rows), d, cap, _ptr(ranks), _stream()),
-           "basd_mp_rank")
+    _check(lib().basd_mp_rank(_ptr(evals), batch, n, ctypes.c_int64(rows), d, cap, _ptr(ranks),
+                              _ptr(status_word(evals.device)), _stream()), "basd_mp_rank")
     return ranks
 
 

@@ -15,11 +15,26 @@
 
 namespace basd {
 
+// Health word (optional, one int32 per launch set, OR-ed with atomics): BASD_STATUS_NONCONVERGED when a matrix used
+// all max_sweeps sweeps and was still rotating, BASD_STATUS_NONFINITE when a singular value is NaN / Inf (a NaN input
+// makes every rotation test false, so such a matrix "converges" at once and would otherwise pass silently).
+__device__ __forceinline__ void report_status(int32_t* status, bool converged, const float* s_sig, int n, int tid,
+                                              int nthreads) {
+  if (!status) return;
+  int st = 0;
+  for (int c = tid; c < n; c += nthreads) {
+    const float v = s_sig[c];
+    if (!(v == v) || v > 3.0e38f) st |= BASD_STATUS_NONFINITE;
+  }
+  if (tid == 0 && !converged) st |= BASD_STATUS_NONCONVERGED;
+  if (st) atomicOr(status, st);
+}
+
 template <int MAXCH>
 __global__ __launch_bounds__(1024) void jacobi_kernel(
     float* __restrict__ wg, int m, int n, int ld, int norm_rows, float tol,
     int max_sweeps, int sort, float* __restrict__ sigma, int32_t* __restrict__ sweeps_out,
-    const int32_t* __restrict__ active, int active_rows) {
+    const int32_t* __restrict__ active, int active_rows, int32_t* __restrict__ status) {
   extern __shared__ __align__(16) float lds[];
   float* W = lds;
   const int tid = threadIdx.x;
@@ -49,6 +64,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
   const int g = tid >> 3, sub = tid & 7;
   const bool has_pair = g < npairs;
   int used_sweeps = 0;
+  bool converged = false;
 
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     bool rotated = false;
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
     const int any = s_flag[sweep & 1];
     if (tid == 0) s_flag[(sweep + 1) & 1] = 0;
     __syncthreads();
-    if (!any) break;
+    if (!any) { converged = true; break; }
   }
 
   // column norms over the first norm_rows rows (one 8-lane group per column, strided)
@@ -147,6 +163,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
     *reinterpret_cast<float4*>(src + (size_t)dst * ld + r) = reinterpret_cast<const float4*>(W)[i];
   }
   if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = used_sweeps;
+  report_status(status, converged, s_sig, n, tid, nthreads);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(NMAT == 2 ? 768 : 1024)
 __attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void jacobi_oe_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
     float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, const int32_t* __restrict__ active,
-    int active_rows) {
+    int active_rows, int32_t* __restrict__ status) {
   extern __shared__ __align__(16) float lds[];
   constexpr int NBUF = (NMAT == 1) ? 2 : 1;
   constexpr int LDM = 32 * MAXCH;                  // mailbox column stride (all MAXCH chunks, no row guards)
@@ -226,6 +243,7 @@ __attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void 
   __syncthreads();
 
   int used_sweeps = 0;
+  bool converged = false;
   int step = 0;                                    // global step counter: even = (2k, 2k+1) view
 #pragma unroll 1
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
@@ -347,7 +365,7 @@ __attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void 
     const int any = s_flag[sweep & 1], anybig = s_flag[2 + (sweep & 1)];
     if (tid == 0) { s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0; }
     __syncthreads();
-    if (!any || !anybig) break;
+    if (!any || !anybig) { converged = true; break; }
   }
   // n_loop is even, so the solve ends in the even view: slot k holds positions 2k (X) and 2k+1 (Y)
 
@@ -419,6 +437,8 @@ __attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void 
       }
     }
     if (sweeps_out && tid == 0) sweeps_out[mat] = used_sweeps;
+    __syncthreads();
+    report_status(status, converged, s_sig, n_tot, tid, blockDim.x);
   }
 }
 
@@ -436,7 +456,7 @@ __attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void 
 template <int MAXCH>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void jacobi_blk_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
-    float* __restrict__ sigma, int32_t* __restrict__ sweeps_out) {
+    float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status) {
   extern __shared__ __align__(16) float lds[];
   constexpr int LDC = 32 * MAXCH;                  // one column in the mailbox
   constexpr int LDB = 2 * LDC;                     // one block
@@ -519,6 +539,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   };
 
   int used_sweeps = 0;
+  bool converged = false;
   int step = 0;                                    // even = blocks (2k, 2k+1); nbe is even, sweeps start and end there
 #pragma unroll 1
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
@@ -610,7 +631,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int any = s_flag[sweep & 1], anybig = s_flag[2 + (sweep & 1)];
     if (tid == 0) { s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0; }
     __syncthreads();
-    if (!any || !anybig) break;
+    if (!any || !anybig) { converged = true; break; }
   }
 
   // ---- singular values = column norms over the first norm_rows rows; phantom columns (id >= n) rank last
@@ -665,13 +686,15 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
   if (sweeps_out && tid == 0) sweeps_out[mat] = used_sweeps;
+  report_status(status, converged, s_sig, n_tot, tid, blockDim.x);
 }
 
 }  // namespace basd
 
 extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
                                float tol, int max_sweeps, int sort, float* sigma,
-                               int32_t* sweeps, const int32_t* active, int active_rows, void* stream) {
+                               int32_t* sweeps, const int32_t* active, int active_rows, int32_t* status,
+                               void* stream) {
   using namespace basd;
   if (batch <= 0) return BASD_OK;
   if (n_cols < 1 || n_cols > BASD_JACOBI_MAX_COLS || ld % 4 != 0 || m_rows > ld || m_rows < 1 ||
@@ -693,7 +716,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   do {                                                                                               \
     allow_full_lds((const void*)jacobi_oe_kernel<MC, NM>);                                            \
     hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
-                       n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows); \
+                       n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows, status); \
   } while (0)
   if (active == nullptr && batch >= 512 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
     // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
@@ -704,7 +727,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   do {                                                                                               \
     allow_full_lds((const void*)jacobi_blk_kernel<MC>);                                              \
     hipLaunchKernelGGL((jacobi_blk_kernel<MC>), dim3(batch), dim3(threads_b), lds_b, st, w, batch, m_rows, n_cols, \
-                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps);                         \
+                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status);                 \
   } while (0)
     if (oe_ch == 2) BASD_LAUNCH_BLK(2);
     else if (oe_ch == 4) BASD_LAUNCH_BLK(4);
@@ -735,7 +758,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     allow_full_lds((const void*)jacobi_kernel<MC>);                                                  \
     hipLaunchKernelGGL(jacobi_kernel<MC>, dim3(batch), dim3(threads), lds_bytes, st, w, m_rows,    \
                        n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active,       \
-                       active_rows);                                                              \
+                       active_rows, status);                                                      \
   } while (0)
   if (chunks <= 2) BASD_LAUNCH_JACOBI(2);
   else if (chunks <= 4) BASD_LAUNCH_JACOBI(4);

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ 
 // Marchenko-Pastur rank, reference src/losses/layer_selector.py:8-20, on device.
 __global__ __launch_bounds__(1024) void mp_rank_kernel(const float* __restrict__ evals, int n,
                                                        float scale, int64_t rows, int d, int cap,
-                                                       int32_t* __restrict__ ranks) {
+                                                       int32_t* __restrict__ ranks, int32_t* __restrict__ status) {
   __shared__ float s_v[1024];
   __shared__ float s_sorted[1024];
   __shared__ int s_count;
@@ -325,7 +325,12 @@ __global__ __launch_bounds__(1024) void mp_rank_kernel(const float* __restrict__
   const float edge = sigma2 * (1.f + sqrtf(q)) * (1.f + sqrtf(q));
   if (tid < n_eff && s_sorted[tid] > edge) atomicAdd(&s_count, 1);
   __syncthreads();
-  if (tid == 0) ranks[blockIdx.x] = s_count < cap ? s_count : cap;
+  if (tid == 0) {
+    ranks[blockIdx.x] = s_count < cap ? s_count : cap;
+    // rank 0 makes the reference divide by sum(sw) = 0 (layer_selector.py:105, NaN weights); a NaN spectrum
+    // compares false everywhere and also counts 0
+    if (status && s_count == 0) atomicOr(status, (sigma2 == sigma2) ? BASD_STATUS_RANK0 : BASD_STATUS_NONFINITE);
+  }
 }
 
 }  // namespace basd
@@ -347,12 +352,12 @@ extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, con
 }
 
 extern "C" int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int cap,
-                            int32_t* ranks, void* stream) {
+                            int32_t* ranks, int32_t* status, void* stream) {
   using namespace basd;
   if (batch <= 0) return BASD_OK;
   if (n < 1 || n > 1024 || rows < 1) return fail(BASD_ERR_SHAPE, "mp_rank: bad shape n=%d", n);
   // eigenvalues handed over are those of X^T X; the reference uses X^T X / M
   hipLaunchKernelGGL(mp_rank_kernel, dim3(batch), dim3(n <= 256 ? 256 : 1024), 0, (hipStream_t)stream, evals, n,
-                     1.0f / (float)rows, rows, d, cap, ranks);
+                     1.0f / (float)rows, rows, d, cap, ranks, status);
   return check_launch("mp_rank");
 }

@@ -2,9 +2,11 @@
 
 The product provider is ``basd_amd._native`` (ctypes over the C-ABI HIP library)
 and it is the ONLY provider this package ever selects: there is no CPU
-fallback.  ``set_ops`` exists so that the CPU test-suite can exercise the host
-logic (autograd formulas, masking, module plumbing) with a test-only emulation
-that lives under ``tests/``; nothing in the package calls it.
+fallback.  ``set_ops`` is the injection point the CPU test-suite uses to exercise
+the host logic (autograd formulas, masking, module plumbing) with its own provider
+(``tests/_emul.py``); nothing in the package calls it or knows about that provider.
+A provider answers ``handles(tensor)``: whether its kernels take this tensor (the HIP
+library: device tensors only).
 """
 from __future__ import annotations
 
@@ -24,8 +26,3 @@ def set_ops(provider) -> None:
     """Tests only."""
     global _ops
     _ops = provider
-
-
-def is_emulated() -> bool:
-    """True only inside the CPU test-suite (a test provider was installed with set_ops)."""
-    return _ops is not None and getattr(_ops, "__name__", "").endswith("_emul")

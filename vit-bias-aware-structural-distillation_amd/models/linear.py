@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..losses._ops import get_ops, is_emulated
+from ..losses._ops import get_ops
 
 
 class _LinearFn(torch.autograd.Function):
@@ -65,7 +65,7 @@ class BasdLinear(nn.Linear):
     def forward(self, x):
         # device tensors only (a CPU module is plain nn.Linear: used by the CPU baseline and by the
         # plumbing tests, which install the test-only kernel emulation)
-        if ((x.is_cuda or is_emulated()) and self.weight.requires_grad and torch.is_grad_enabled() and x.dim() >= 2
+        if (get_ops().handles(x) and self.weight.requires_grad and torch.is_grad_enabled() and x.dim() >= 2
                 and get_ops().wgrad_supported(self.out_features, self.in_features)
                 and x.numel() // x.shape[-1] >= 64):
             with torch.autocast(device_type=x.device.type, enabled=False):

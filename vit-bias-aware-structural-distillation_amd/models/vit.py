@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
-from ..losses._ops import get_ops, is_emulated
+from ..losses._ops import get_ops
 from .linear import BasdLinear
 
 
@@ -99,7 +99,7 @@ class MixedLayerNorm(nn.LayerNorm):
         pre = getattr(x, "_basd_prenorm", None)
         if pre is not None and pre[0] is self and not torch.is_grad_enabled():
             return pre[1]               # already produced by the fused residual-add + norm of the previous step
-        if (x.dtype == torch.bfloat16 and (x.is_cuda or is_emulated()) and self.elementwise_affine
+        if (x.dtype == torch.bfloat16 and get_ops().handles(x) and self.elementwise_affine
                 and get_ops().layernorm_supported(x.shape[-1])):
             return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
@@ -169,7 +169,7 @@ class Attention(nn.Module):
         b, t, c = x.shape
         qkv_flat = self.qkv(x)
         if (_FUSED_TEACHER_ATTENTION and not torch.is_grad_enabled() and qkv_flat.dtype == torch.bfloat16
-                and (qkv_flat.is_cuda or is_emulated()) and get_ops().attention_fwd_supported(t, self.head_dim)):
+                and get_ops().handles(qkv_flat) and get_ops().attention_fwd_supported(t, self.head_dim)):
             # frozen block: fused attention straight from the packed projection, the tap as a by-product
             # (csrc/attention.hip)
             want = self.tap is not None and bool(self.tap["has_cls"]) and t >= 2
@@ -184,7 +184,7 @@ class Attention(nn.Module):
         qkv = qkv_flat.reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
         if self.tap is not None:
-            ops = get_ops() if (qkv_flat.is_cuda or is_emulated()) else None
+            ops = get_ops() if get_ops().handles(qkv_flat) else None
             if (ops is not None and self.tap["has_cls"] and qkv_flat.dtype == torch.bfloat16
                     and ops.cls_importance_supported(t, self.head_dim)):
                 # fused tap: streams K once from the packed projection (csrc/attn_tap.hip)
@@ -242,7 +242,7 @@ class Block(nn.Module):
 
     def _fused_inference(self, x) -> bool:
         """frozen pre-norm block on bf16 activations: the residual adds fuse into the following norms"""
-        return (not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and (x.is_cuda or is_emulated())
+        return (not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and get_ops().handles(x)
                 and isinstance(self.ls1, nn.Identity) and isinstance(self.ls2, nn.Identity)
                 and (not self.training or (self.drop_path1.p == 0.0 and self.drop_path2.p == 0.0))
                 and self.norm2.elementwise_affine and get_ops().layernorm_supported(x.shape[-1]))

@@ -19,6 +19,7 @@ from pathlib import Path
 import torch
 import torch.nn as nn
 
+from ..losses._ops import get_ops
 from ..losses.combined import BASDLoss
 from ..models.teacher import TeacherModel, extract_intermediates
 from .data_parallel import GradientReducer
@@ -84,6 +85,8 @@ class Trainer:
         self._side = None
         self._graph = None
         self.graph_error = None
+        self._status_host = None        # pinned copy of the kernels' health word, read one step late
+        self._status_event = None
 
     def _side_stream(self):
         if self.device.type != "cuda" or not self.overlap_teacher_stats:
@@ -198,8 +201,36 @@ class Trainer:
             self.flat.zero_grad()
             return False
 
+    # ---------------------------------------------------------------- health
+    def _poll_status(self) -> None:
+        """Raise (BasdLinAlgError, a torch.linalg.LinAlgError) if a kernel of the PREVIOUS step flagged non-finite
+        input, a Jacobi solve without convergence or a rank-0 teacher layer.  The reference raises from inside
+        torch.linalg with a host sync per call; here the flags are OR-ed into one device word, copied to pinned
+        memory after the step and looked at when the next step starts: no sync inside the step."""
+        if self._status_event is None:
+            return
+        self._status_event.synchronize()
+        self._status_event = None
+        get_ops().raise_for_status(int(self._status_host[0]))
+
+    def _post_status(self) -> None:
+        ops = get_ops()
+        word = ops.status_word(self.device)
+        if self._status_host is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32)
+            if self.device.type == "cuda":
+                self._status_host = self._status_host.pin_memory()
+        self._status_host.copy_(word, non_blocking=True)
+        word.zero_()
+        if self.device.type == "cuda":
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
+        else:
+            get_ops().raise_for_status(int(self._status_host[0]))
+
     def train_step(self, batch: dict):
         """One optimisation step on a device-resident batch {"clean","augmented","label"}."""
+        self._poll_status()
         clean, student_imgs, targets = batch["clean"], batch["augmented"], batch["label"]
         if self.use_mixup:
             student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
@@ -217,6 +248,7 @@ class Trainer:
         else:
             loss, logits = self._forward_backward(clean, student_imgs, mixed_targets)
             self.reducer.finish()
+        self._post_status()
         self.optimizer.step()
         self.optimizer.zero_grad()
         return loss, logits
