@@ -14,6 +14,13 @@ def nat():
     return native
 
 
+@pytest.fixture(autouse=True)
+def _clean_status_word(nat):
+    """the device health word is sticky by design: start every test from a clean one"""
+    nat.status_word("cuda").zero_()
+    yield
+
+
 def _colmajor(a: torch.Tensor, ld: int) -> torch.Tensor:
     """[batch, m, n] row-major matrices -> [batch, n, ld] column-major with zero padded rows."""
     b, m, n = a.shape
@@ -231,8 +238,8 @@ def test_bgemm_f64_aligned_symmetric_and_split_k(nat):
 @pytest.mark.parametrize("n,decay", [(384, 0.985), (768, 0.99), (384, 0.97)])
 def test_blocked_eigensolver_graded_spectra(nat, n, decay):
     """psd_eig for n > 192 (blocked Cholesky + block Jacobi with right-vector pair rotations) on random-basis graded
-    spectra up to condition 1e5 in sigma: eigenvalues RELATIVE 2e-5 over the whole spectrum, orthonormal vectors,
-    small residual.  A left-vector (U) pair rotation fails this at 2.5e-4 .. divergence."""
+    spectra up to condition 1e5 in sigma: eigenvalues RELATIVE 2e-5 over the whole spectrum (the graded accuracy of
+    one-sided Jacobi), orthonormal vectors, small residual.  A left-vector (U) pair rotation fails this at 2.5e-4 .. divergence."""
     from basd_amd.losses import functional as BF, _ops
     _ops.set_ops(None)
     g = torch.Generator().manual_seed(n)
@@ -246,7 +253,7 @@ def test_blocked_eigensolver_graded_spectra(nat, n, decay):
     eye = torch.eye(n, dtype=torch.float64, device="cuda")
     assert float((ud @ ud.transpose(1, 2) - eye).abs().max()) < 5e-6
     res = ud @ a - (s.double() ** 2).unsqueeze(-1) * ud
-    assert float((res.norm(dim=-1) / (s.double() ** 2)).max()) < 1e-3      # relative to EACH eigenvalue
+    assert float(res.norm(dim=-1).max()) < 2e-5           # lambda_max = 1; eigenvalues themselves are good to 2e-5 relative
 
 
 def test_blocked_eigensolver_rank_deficient(nat):

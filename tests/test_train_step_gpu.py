@@ -45,8 +45,8 @@ def test_c1_step_matches_the_cpu_oracle_step():
     """One BASELINE-c1-size step (DeiT-T / ViT-S, 32x32, patch 4) on the HIP path against the CPU restatement of the
     whole step (oracle/cpu_step.py: plain fp32 torch ViTs + the oracle loss pinned to the reference) on IDENTICAL
     weights, projections and images: ranks exact, mixing weights, loss terms, and the gradient of every student
-    parameter.  The GPU path runs bf16 activations (the CPU one fp32), which sets the tolerances: loss terms 1 %,
-    flat gradient: norm within 3 %, cosine > 0.995."""
+    parameter.  The GPU path runs bf16 activations (the CPU one fp32), which sets the tolerances: loss terms 1 %
+    (measured 6e-4), flat gradient: norm within 1 % (measured 1e-3), cosine > 0.998."""
     from basd_amd.models.vit import create_vit
     from oracle.cpu_step import reference_loss_backward
     trainer, batch = _make(32)
@@ -81,12 +81,12 @@ def test_c1_step_matches_the_cpu_oracle_step():
     for name, p in trainer.model.named_parameters():
         got.append(p.grad.detach().float().cpu().flatten())
         ref.append(cpu_params[name].grad.flatten())
-    got, ref = torch.cat(got), torch.cat(ref)
+    got, ref = torch.cat(got).double(), torch.cat(ref).double()
     cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
     print(f"step-level: loss {float(loss):.5f} vs {float(want['loss']):.5f}; |g| {float(got.norm()):.4e} vs "
           f"{float(ref.norm()):.4e}; cosine {cos:.5f}")
-    assert abs(float(got.norm()) - float(ref.norm())) <= 3e-2 * float(ref.norm())
-    assert cos > 0.995
+    assert abs(float(got.norm()) - float(ref.norm())) <= 1e-2 * float(ref.norm())     # measured 1e-3
+    assert cos > 0.998
     g_t = sel.log_temperatures.grad.detach().cpu()
     torch.testing.assert_close(g_t, log_t.grad, rtol=5e-2, atol=1e-6)
 
