@@ -97,10 +97,29 @@ def test_checkpoint_roundtrip(tmp_path):
         trainer.train_step(batch)
     trainer.save_checkpoint("latest", 0)
     trainer.save_weights("final_model.pth", 0)
+    ckpt = tmp_path / cfg.run.name / "checkpoints" / "latest"
+    # the on-disk layout of accelerator.save_state + the reference's custom_state.pth
+    assert sorted(p.name for p in ckpt.iterdir()) == ["custom_checkpoint_0.pkl", "custom_state.pth", "model.safetensors",
+                                                      "optimizer.bin", "random_states_0.pkl"]
+    sel = trainer.basd_loss.layer_selector
     snap = trainer.flat.data.clone()
+    snap_z, snap_v, snap_k = trainer.optimizer.z.clone(), trainer.optimizer.exp_avg_sq.clone(), trainer.optimizer.k
+    snap_ps, snap_pt = sel.proj_s.clone(), sel.proj_t.clone()
+    # a "different run": other weights, other optimizer state, other random projections (another seed)
     trainer.flat.data.add_(1.0)
-    assert trainer.load_checkpoint(str(tmp_path / cfg.run.name / "checkpoints" / "latest")) == 1
-    torch.testing.assert_close(trainer.flat.data, snap)
+    trainer.optimizer.z.zero_()
+    trainer.optimizer.exp_avg_sq.add_(3.0)
+    trainer.optimizer.k = 17
+    torch.nn.init.orthogonal_(sel.proj_s)
+    torch.nn.init.orthogonal_(sel.proj_t)
+    assert trainer.load_checkpoint(str(ckpt)) == 1
+    torch.testing.assert_close(trainer.flat.data, snap, rtol=0, atol=0)
+    torch.testing.assert_close(trainer.optimizer.z, snap_z, rtol=0, atol=0)
+    torch.testing.assert_close(trainer.optimizer.exp_avg_sq, snap_v, rtol=0, atol=0)
+    assert trainer.optimizer.k == snap_k
+    torch.testing.assert_close(sel.proj_s, snap_ps, rtol=0, atol=0)
+    torch.testing.assert_close(sel.proj_t, snap_pt, rtol=0, atol=0)
+    torch.testing.assert_close(trainer.flat.data16.float(), snap.bfloat16().float(), rtol=0, atol=0)   # shadow refreshed
     sd = torch.load(tmp_path / cfg.run.name / "checkpoints" / "final_model.pth", weights_only=True)
     assert "blocks.0.attn.qkv.weight" in sd["model_state_dict"] and "cls_token" in sd["model_state_dict"]
 

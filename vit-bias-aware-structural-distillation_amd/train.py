@@ -116,7 +116,11 @@ def main(argv=None):
     print(f"student_probed embed_dim={info['embed_dim']} depth={info['depth']} num_tokens={info['num_tokens']}")
     loader = SyntheticLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes,
                              args.steps_per_epoch, trainer.device)
-    trainer.train(loader, None, start_epoch=0)
+    start_epoch = 0
+    if config.checkpoint.get("resume_from"):            # reference src/train.py:147-149
+        start_epoch = trainer.load_checkpoint(config.checkpoint.resume_from)
+        print(f"resumed_from={config.checkpoint.resume_from} start_epoch={start_epoch}")
+    trainer.train(loader, None, start_epoch=start_epoch)
 
 
 if __name__ == "__main__":

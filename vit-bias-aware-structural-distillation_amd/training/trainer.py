@@ -293,10 +293,25 @@ class Trainer:
         return d
 
     def save_checkpoint(self, name: str, epoch: int) -> None:
+        """``checkpoints/<name>/`` in the layout ``accelerator.save_state`` writes for the reference
+        (src/training/trainer.py:94-103 with ``register_for_checkpointing(basd_loss)`` :84; file names of
+        accelerate 1.x: ``model.safetensors``, ``optimizer.bin``, ``custom_checkpoint_0.pkl`` = the registered
+        BASDLoss state dict, ``random_states_0.pkl``) plus the reference's own ``custom_state.pth``."""
+        import random
+
+        import numpy as np
+        from safetensors.torch import save_file
         d = self._ckpt_dir() / name
         d.mkdir(parents=True, exist_ok=True)
-        torch.save({"model": self.model.state_dict(), "basd_loss": self.basd_loss.state_dict(),
-                    "optimizer": self.optimizer.state_dict()}, d / "state.pth")
+        save_file({k: v.detach().contiguous().cpu() for k, v in self.model.state_dict().items()}, str(d / "model.safetensors"))
+        torch.save({k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()},
+                   d / "optimizer.bin")
+        torch.save({k: v.detach().cpu() for k, v in self.basd_loss.state_dict().items()}, d / "custom_checkpoint_0.pkl")
+        rng = {"random_state": random.getstate(), "numpy_random_seed": np.random.get_state(),
+               "torch_manual_seed": torch.get_rng_state()}
+        if self.device.type == "cuda":
+            rng["torch_cuda_manual_seed"] = torch.cuda.get_rng_state_all()
+        torch.save(rng, d / "random_states_0.pkl")
         torch.save({"epoch": epoch, "best_val_acc": self.best_val_acc,
                     "metrics_history": dict(self.metrics_history)}, d / "custom_state.pth")
 
@@ -304,10 +319,31 @@ class Trainer:
         torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()}, self._ckpt_dir() / filename)
 
     def load_checkpoint(self, checkpoint_path: str) -> int:
+        """Restore EVERYTHING ``save_checkpoint`` wrote (reference :113-123 -> ``accelerator.load_state``): student
+        weights, the loss module's state (``log_temperatures`` and the random-orthogonal ``proj_s`` / ``proj_t``
+        buffers -- a resume with another seed must not change the selector's projections), optimizer state, RNG
+        streams; then the bf16 shadow of the weights is refreshed.  Tensors are loaded with ``weights_only=True``."""
+        import random
+
+        import numpy as np
+        from safetensors.torch import load_file
         d = Path(checkpoint_path)
-        state = torch.load(d / "state.pth", map_location=self.device, weights_only=False)
-        self.optimizer.load_state_dict(state["optimizer"])     # flat buffer: restores every parameter
-        custom = torch.load(d / "custom_state.pth", map_location=self.device, weights_only=False)
+        self.model.load_state_dict(load_file(str(d / "model.safetensors"), device=str(self.device)))
+        self.basd_loss.load_state_dict(torch.load(d / "custom_checkpoint_0.pkl", map_location=self.device,
+                                                  weights_only=True))
+        # parameters are views of the flat buffer: the two loads above already wrote into it; the optimizer state
+        # carries the same buffer (train-mode "y" point) plus z, v and the step counters
+        self.optimizer.load_state_dict(torch.load(d / "optimizer.bin", map_location=self.device, weights_only=True))
+        self.flat.refresh_bf16()
+        rng_file = d / "random_states_0.pkl"
+        if rng_file.exists():
+            rng = torch.load(rng_file, map_location="cpu", weights_only=False)   # python / numpy state tuples
+            random.setstate(rng["random_state"])
+            np.random.set_state(rng["numpy_random_seed"])
+            torch.set_rng_state(rng["torch_manual_seed"])
+            if self.device.type == "cuda" and "torch_cuda_manual_seed" in rng:
+                torch.cuda.set_rng_state_all(rng["torch_cuda_manual_seed"])
+        custom = torch.load(d / "custom_state.pth", map_location=self.device, weights_only=True)
         self.best_val_acc = custom["best_val_acc"]
         self.metrics_history = defaultdict(list, custom["metrics_history"])
         return custom["epoch"] + 1
