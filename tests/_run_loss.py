@@ -41,7 +41,8 @@ def check_against_golden(gold, res, kind, layers, *, grad_tol, has_temp_grad=Tru
     from tests._golden import rel_l2
     assert res["ranks"].tolist() == gold[f"{kind}/ranks"].tolist()
     torch.testing.assert_close(res["weights"], gold[f"{kind}/weights"], atol=2e-6, rtol=0)
-    torch.testing.assert_close(res["pre_softmax"], gold[f"{kind}/pre_softmax"], atol=2e-5, rtol=1e-4)
+    if gold[f"{kind}/weights"].shape[1] > 1:      # a single teacher layer: the distance is never formed (weight == 1)
+        torch.testing.assert_close(res["pre_softmax"], gold[f"{kind}/pre_softmax"], atol=2e-5, rtol=1e-4)
     print("  geo rel err", ((res["geo"] - gold[f"{kind}/geo"]).abs() / gold[f"{kind}/geo"].abs()).tolist(), "weights max abs err", float((res["weights"] - gold[f"{kind}/weights"]).abs().max()))
     torch.testing.assert_close(res["geo"], gold[f"{kind}/geo"], atol=0, rtol=geo_rtol)
     torch.testing.assert_close(res["ce"], gold[f"{kind}/ce"], atol=0, rtol=1e-5)

@@ -70,20 +70,73 @@ def test_c1_train_steps_run_and_learn_on_cpu():
     assert not torch.allclose(lt.detach(), torch.full_like(lt, 0.5413248546129181))
 
 
+def _full_map_recorder(store: dict, key):
+    """Checker only: what the reference's attention hook records (src/models/teacher.py:27-39) -- the FULL softmax map
+    of an attention module, recomputed from the module's input through its own qkv projection."""
+    def record(module, args, output):
+        tokens = args[0]
+        heads = module.num_heads
+        q, k, _ = module.qkv(tokens).unflatten(-1, (3, heads, -1)).permute(2, 0, 3, 1, 4)
+        store[key] = torch.softmax(q @ k.transpose(-2, -1) * q.shape[-1] ** -0.5, dim=-1)
+    return record
+
+
 def test_teacher_tap_equals_full_attention_map():
-    """importance tap == CLS row (head mean) of the map the reference hook builds."""
-    from basd_amd.models import extract_intermediates, load_teacher, make_attn_capture_hook
+    """importance tap == CLS row (head mean) of the full map a reference-style hook records."""
+    from basd_amd.models import extract_intermediates, load_teacher
     t = load_teacher("vit_small_patch16_224", 32, device="cpu", patch_size=4, dtype=torch.float32)
     x = torch.randn(3, 3, 32, 32)
     maps, hooks = {}, []
     for i, path in enumerate(t.layer_paths):
-        hooks.append(t.model.get_submodule(f"{path}.attn").register_forward_hook(make_attn_capture_hook(maps, i)))
+        hooks.append(t.model.get_submodule(f"{path}.attn").register_forward_hook(_full_map_recorder(maps, i)))
     tokens, imp = extract_intermediates(t, x)
     for h in hooks:
         h.remove()
     assert sorted(tokens) == list(range(12)) and tokens[0].shape == (3, 64, 384)
     for i in range(12):
         torch.testing.assert_close(imp[i], maps[i][:, :, 0, 1:].mean(1), atol=1e-6, rtol=1e-5)
+
+
+def test_probe_finds_vit_blocks_and_resnet_stages():
+    """probe_model: the reference's key set; ViT `blocks`, and the `layer1..4` family of ResNets its probe cannot see"""
+    from basd_amd.models import probe_model
+    from basd_amd.models.cnn import create_cnn
+    from basd_amd.models.vit import create_vit
+    vit = probe_model(create_vit("deit_small_patch16_224", num_classes=10, img_size=32, patch_size=4), 32)
+    assert vit == {"embed_dim": 384, "heads_per_layer": [6] * 12, "depth": 12, "mlp_ratio": 4.0,
+                   "layer_paths": [f"blocks.{i}" for i in range(12)], "attn_subpath": "attn", "has_cls_token": True,
+                   "feature_format": "token", "num_tokens": 64}
+    cnn = probe_model(create_cnn("resnet50"), 64)
+    assert cnn["layer_paths"] == ["layer1", "layer2", "layer3", "layer4"] and cnn["feature_format"] == "nchw"
+    assert cnn["embed_dim"] == 2048 and cnn["heads_per_layer"] == [1] and not cnn["has_cls_token"]
+    assert cnn["attn_subpath"] is None and cnn["num_tokens"] == 0
+
+
+def test_cnn_teacher_step_runs_on_cpu():
+    """BASELINE c3 plumbing (ResNet-50 teacher: one layer of 2 x 2 = 4 tokens x 2048 channels at 64 px, uniform
+    importance, resampled to the student's 16 tokens): the selector degenerates to weight 1 and a zero temperature
+    gradient ("c3 degenerates, exactly")"""
+    from basd_amd.config import load_config
+    from basd_amd.models import extract_intermediates
+    from basd_amd.train import SyntheticLoader, build
+    torch.manual_seed(0)
+    cfg = load_config(CFG, None, ["data.batch_size=8", "data.dataset=synthetic", "model.num_classes=10",
+                                  "model.vit.img_size=64", "model.vit.patch_size=16", "model.drop_path_rate=0.0",
+                                  "basd.teacher_model_name=resnet50"])
+    trainer, info = build(cfg, device="cpu")
+    assert trainer._teacher.feature_format == "nchw" and trainer._teacher.embed_dim == 2048
+    batch = next(iter(SyntheticLoader(8, 64, 10, 1, "cpu")))
+    tok, imp = extract_intermediates(trainer._teacher, batch["clean"])
+    assert list(tok) == [0] and tok[0].shape == (8, 4, 2048) and torch.allclose(imp[0], torch.full((8, 4), 0.25))
+    trainer.use_mixup = False
+    trainer.optimizer.train()
+    trainer.model.train()
+    loss, logits = trainer._forward_backward(batch["clean"], batch["augmented"], batch["label"])
+    assert torch.isfinite(loss) and logits.shape == (8, 10)
+    sel = trainer.basd_loss.layer_selector
+    torch.testing.assert_close(sel.last_weights, torch.ones(4, 1))
+    assert float(sel.log_temperatures.grad.abs().max()) == 0.0
+    assert float(trainer.flat.grad.abs().max()) > 0.0
 
 
 def test_checkpoint_roundtrip(tmp_path):

@@ -228,6 +228,19 @@ def teacher_frames(teacher_tokens, proj_t, grams=None):
 
 
 @torch.no_grad()
+def teacher_ranks(teacher_tokens, proj_t) -> torch.Tensor:
+    """MP ranks only (device int32 [L]): all a single-layer teacher needs -- with one teacher layer the softmax over
+    layers is the constant 1 (reference layer_selector.py:108), so neither PCA frames nor principal angles nor the
+    student's eigen-decompositions influence value or gradient ("c3 degenerates, exactly")."""
+    ops = get_ops()
+    D = proj_t.shape[0]
+    m_t = teacher_tokens[0].shape[0] * teacher_tokens[0].shape[1]
+    unc = torch.stack([ops.token_gram(x, proj_t, mirror=False)[0] for x in teacher_tokens])
+    sigma, _, _ = psd_eig(unc, lower_only=True)
+    return ops.mp_rank(sigma ** 2, m_t, D, D - 1)
+
+
+@torch.no_grad()
 def student_frames(student_tokens, proj_s):
     """Student half of the selector statistics (centred Gram eigen-decomposition per extraction point):
     (sigma [E, D], v [E, D, D]).  No gradient flows through these tensors themselves -- the selector backward

@@ -36,8 +36,10 @@ def marchenko_pastur_rank(features: torch.Tensor) -> int:
     """
     ops = get_ops()
     m, d = features.shape
-    if d % 16 or d > 256 or d < 32:
-        raise BF.BasdShapeError(f"marchenko_pastur_rank: D={d} must be a multiple of 16 in [32, 256]")
+    if d > 1024:
+        raise BF.BasdShapeError(f"marchenko_pastur_rank: D={d} > 1024 (the device rank count sorts up to 1024 values)")
+    # X^T X in fp64: the fused one-pass kernel up to 256 columns, projection-free split-K fp64 MFMA GEMM beyond
+    # (ViT-B .. ViT-H teachers: D_t = 768 .. 1280 -> 1024 is covered; the eigen-solve is the blocked one for D > 192)
     eye = torch.eye(d, device=features.device, dtype=torch.float32)
     gram, _ = ops.token_gram(features.contiguous(), eye)
     sigma, _, _ = BF.psd_eig(gram.unsqueeze(0))
@@ -122,6 +124,16 @@ class GrassmannianLayerSelector(nn.Module):
                 self._frames[1]["ready"]()           # unused precomputation: still join its stream
         self._frames = None
         s_list = [student_tokens_per_layer[l] for l in extraction_indices]
+        if len(teacher_indices) == 1 and frames is None:
+            # single-layer (CNN) teacher: softmax over one layer == 1 exactly, no gradient reaches the student or the
+            # temperatures through the selector; only the rank (a reported attribute) is computed
+            ranks = BF.teacher_ranks([all_teacher_tokens[teacher_indices[0]].detach()], self.proj_t)
+            # (softmax of a single logit: the temperatures receive an exactly-zero gradient, not None, as in the reference)
+            weights = torch.softmax(0.0 * self.log_temperatures.float().view(-1, 1), dim=1)
+            self._ranks_dev, self._rank_keys = ranks, teacher_indices
+            self.last_weights, self.last_pre_softmax = weights.detach(), torch.zeros_like(weights.detach())
+            self._student_pre = None
+            return weights, teacher_indices
         pre_s, self._student_pre = getattr(self, "_student_pre", None), None
         if pre_s is not None:
             pre_s = pre_s[1] if pre_s[0] == [id(t) for t in s_list] else None

@@ -1,3 +1,3 @@
 from .teacher import (TeacherModel, estimate_intrinsic_dim, extract_intermediates, load_teacher,  # noqa: F401
-                      make_attn_capture_hook, probe_model)
+                      probe_model)
 from .vit import VisionTransformer, create_vit, VIT_PRESETS  # noqa: F401

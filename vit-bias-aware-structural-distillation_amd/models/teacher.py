@@ -1,9 +1,11 @@
 """Teacher handling: architecture probe, per-block token + importance tap.
 
 Mirrors the operator surface of reference ``src/models/teacher.py``
-(``TeacherModel`` :9-20, ``make_attn_capture_hook`` :27-39, ``probe_model``
-:42-110, ``load_teacher`` :113-148, ``_to_token_format`` :151-158,
-``estimate_intrinsic_dim`` :161-177, ``extract_intermediates`` :180-216).
+(``TeacherModel`` :9-20, ``probe_model`` :42-110, ``load_teacher`` :113-148,
+``_to_token_format`` :151-158, ``estimate_intrinsic_dim`` :161-177,
+``extract_intermediates`` :180-216).  The reference's full-map attention hook
+(``make_attn_capture_hook`` :27-39) has no counterpart in the product: the blocks emit
+the CLS-row importance themselves; a reference-style hook lives in ``tests/`` as a checker.
 
 * ``extract_intermediates`` returns ``(tokens {j: [B,N,D]}, importance
   {j: [B,N]})``: the second dict holds the head-averaged CLS-row (or
@@ -43,84 +45,81 @@ _IMAGENET_MEAN = (0.485, 0.456, 0.406)
 _IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def make_attn_capture_hook(capture_dict: dict, layer_idx: int, *, apply_softmax: bool = True):
-    """Reference-compatible forward hook that stores the FULL map (teacher.py:27-39).
+_STAGE_CONTAINERS = ("blocks", "layers", "stages")
 
-    Kept for callers of the reference surface / for tests; the train step uses the
-    in-block importance tap instead.
-    """
-    def hook(mod, inp, out):
-        x_in = inp[0]
-        b, n, c = x_in.shape
-        nh = mod.num_heads
-        hd = c // nh
-        qkv = mod.qkv(x_in).reshape(b, n, 3, nh, hd).permute(2, 0, 3, 1, 4)
-        attn = (qkv[0] @ qkv[1].transpose(-2, -1)) * (hd ** -0.5)
-        capture_dict[layer_idx] = attn.softmax(dim=-1) if apply_softmax else attn
-    return hook
+
+def _stage_paths(model: nn.Module) -> list[str]:
+    """Module paths of the model's repeated stages, in execution order: the children of a ``blocks`` / ``layers`` /
+    ``stages`` container (ViT, Swin, ConvNeXt: what the reference's probe looks for, teacher.py:46-50), or the numbered
+    attribute family ``layer1, layer2, ...`` of torchvision / timm ResNets, which the reference's probe cannot see
+    ("c3")."""
+    children = dict(model.named_children())
+    for name in _STAGE_CONTAINERS:
+        box = children.get(name)
+        if isinstance(box, (nn.Sequential, nn.ModuleList)) and len(box) > 0:
+            return [f"{name}.{i}" for i in range(len(box))]
+    numbered = sorted((int(n[5:]), n) for n in children if n.startswith("layer") and n[5:].isdigit())
+    if numbered and [i for i, _ in numbered] == list(range(numbered[0][0], numbered[0][0] + len(numbered))):
+        return [n for _, n in numbered]
+    raise ValueError("probe_model: no block container (blocks / layers / stages) and no layer1..N stage family found")
 
 
 def probe_model(model: nn.Module, img_size: int) -> dict:
-    """Same keys as the reference probe (teacher.py:100-110); runs on the model's own device."""
-    embed_dim = getattr(model, "embed_dim", None) or getattr(model, "num_features", None)
-    layer_paths = []
-    for name in ("blocks", "layers", "stages"):
-        container = getattr(model, name, None)
-        if isinstance(container, (nn.Sequential, nn.ModuleList)):
-            layer_paths = [f"{name}.{i}" for i in range(len(container))]
-            break
-    attn_subpath, heads_per_layer, mlp_ratio = None, [], 0.0
+    """Architecture record with the reference's keys (teacher.py:100-110): ``embed_dim, heads_per_layer, depth,
+    mlp_ratio, layer_paths, attn_subpath, has_cls_token, feature_format, num_tokens``.  One pass over the stage
+    modules collects heads / MLP width, one forward of a zero image through a hook on the LAST stage tells the
+    feature format (token / nchw / nhwc) and the token count.  Runs on the model's own device."""
+    layer_paths = _stage_paths(model)
+    width = getattr(model, "embed_dim", None) or getattr(model, "num_features", None)
+    heads, attn_name, hidden = [], None, None
     for path in layer_paths:
-        block = model.get_submodule(path)
-        block_heads = 0
-        for child_name, child in block.named_children():
-            if hasattr(child, "num_heads"):
-                attn_subpath = attn_subpath or child_name
-                block_heads = child.num_heads
-                break
-        heads_per_layer.append(block_heads)
-        if mlp_ratio == 0.0:
-            for _, child in block.named_children():
-                if hasattr(child, "fc1"):
-                    mlp_ratio = child.fc1.out_features / embed_dim
-                    break
-    has_cls_token = any(n == "cls_token" for n, _ in model.named_parameters())
-    dev = next(model.parameters()).device
-    probe = torch.zeros(1, 3, img_size, img_size, device=dev)
-    num_tokens = 0
-    was_training = model.training
+        stage = model.get_submodule(path)
+        attn = next(((n, m) for n, m in stage.named_children() if hasattr(m, "num_heads")), None)
+        heads.append(attn[1].num_heads if attn else 0)
+        attn_name = attn_name or (attn[0] if attn else None)
+        if hidden is None:
+            hidden = next((m.fc1.out_features for m in stage.children() if hasattr(m, "fc1")), None)
+    has_cls = isinstance(getattr(model, "cls_token", None), nn.Parameter)
+    seen = []
+    hook = model.get_submodule(layer_paths[-1]).register_forward_hook(lambda m, i, o: seen.append(o))
+    first = next(model.parameters())
+    mode = model.training
     model.eval()
-    with torch.no_grad():
-        captured = {}
-        mod = model.get_submodule(layer_paths[-1])
-        h = mod.register_forward_hook(lambda m, i, o: captured.update(out=o))
-        model(probe)
-        h.remove()
-        out = captured["out"]
-        if out.dim() == 4:
-            feature_format = "nchw" if out.shape[1] > out.shape[3] else "nhwc"
-        else:
-            feature_format = "token"
-            num_tokens = out.shape[1] - int(has_cls_token)
-    model.train(was_training)
-    if feature_format != "token":
-        heads_per_layer = [1]
+    try:
+        with torch.no_grad():
+            model(torch.zeros(1, 3, img_size, img_size, device=first.device, dtype=first.dtype))
+    finally:
+        hook.remove()
+        model.train(mode)
+    out = seen[-1]
+    if out.dim() == 4:                      # conv feature map: channels are the long axis next to the batch (nchw) or last
+        fmt, n_tok = ("nchw" if out.shape[1] > out.shape[3] else "nhwc"), 0
+        heads = [1]
+        width = width or (out.shape[1] if fmt == "nchw" else out.shape[3])
+    else:
+        fmt, n_tok = "token", out.shape[1] - int(has_cls)
     return {
-        "embed_dim": embed_dim, "heads_per_layer": heads_per_layer, "depth": len(layer_paths),
-        "mlp_ratio": mlp_ratio, "layer_paths": layer_paths, "attn_subpath": attn_subpath,
-        "has_cls_token": has_cls_token, "feature_format": feature_format, "num_tokens": num_tokens,
+        "embed_dim": width, "heads_per_layer": heads, "depth": len(layer_paths),
+        "mlp_ratio": (hidden / width) if hidden else 0.0, "layer_paths": layer_paths, "attn_subpath": attn_name,
+        "has_cls_token": has_cls, "feature_format": fmt, "num_tokens": n_tok,
     }
 
 
 def load_teacher(model_name: str, img_size: int, *, weights: str | None = None, device="cuda",
                  seed: int = 42, patch_size: int | None = None, dtype=torch.bfloat16) -> TeacherModel:
-    """Build (not download) the named teacher, frozen, in eval mode, weights pre-cast to bf16."""
-    if model_name not in VIT_PRESETS:
-        raise ValueError(f"teacher {model_name!r} is not a known ViT preset (CNN teachers: pass your own "
-                         "module to TeacherModel, feature_format 'nchw'/'nhwc')")
+    """Build (not download: reference teacher.py:113-148 fetches from the network) the named teacher -- a ViT preset of
+    ``models/vit.py`` or a CNN preset of ``models/cnn.py`` -- frozen, in eval mode, weights pre-cast to bf16; ``weights``
+    = a local state dict (timm / torchvision parameter names)."""
+    from .cnn import CNN_PRESETS, create_cnn
     gen_state = torch.random.get_rng_state()
     torch.manual_seed(seed)
-    model = create_vit(model_name, num_classes=0, img_size=img_size, patch_size=patch_size)
+    if model_name in VIT_PRESETS:
+        model = create_vit(model_name, num_classes=0, img_size=img_size, patch_size=patch_size)
+    elif model_name in CNN_PRESETS:
+        model = create_cnn(model_name)
+    else:
+        raise ValueError(f"teacher {model_name!r}: not a known preset ({sorted(VIT_PRESETS) + sorted(CNN_PRESETS)}); "
+                         "wrap your own module in TeacherModel(...) with the fields probe_model() returns")
     torch.random.set_rng_state(gen_state)
     if weights:
         state = torch.load(weights, map_location="cpu", weights_only=True)
@@ -130,6 +129,8 @@ def load_teacher(model_name: str, img_size: int, *, weights: str | None = None, 
         p.requires_grad = False
     info = probe_model(model, img_size)
     model = model.to(dtype)
+    if info["feature_format"] != "token" and torch.device(device).type == "cuda":
+        model = model.to(memory_format=torch.channels_last)
     for m in model.modules():           # LayerNorm parameters stay fp32 (autocast semantics); the fused
         if isinstance(m, nn.LayerNorm):   # kernel takes bf16 activations with fp32 gamma / beta
             m.float()
@@ -151,13 +152,13 @@ def _to_token_format(t: torch.Tensor, feature_format: str, has_cls_token: bool) 
 
 @torch.no_grad()
 def estimate_intrinsic_dim(teacher: TeacherModel, images: torch.Tensor) -> int:
-    captured = {}
-    mod = teacher.model.get_submodule(teacher.layer_paths[-1])
-    h = mod.register_forward_hook(lambda m, i, o: captured.update(out=o))
-    teacher.model(images.to(next(teacher.model.parameters()).dtype))
-    h.remove()
-    tokens = _to_token_format(captured["out"], teacher.feature_format, teacher.has_cls_token)
-    return marchenko_pastur_rank(tokens.reshape(-1, tokens.shape[-1]).float())
+    """Marchenko-Pastur rank of the teacher's LAST-stage tokens over a calibration batch (reference
+    teacher.py:161-177; feeds ``_derive_from_teacher``, src/train.py:57-66).  The last stage's tokens are exactly what
+    ``extract_intermediates`` returns for its highest layer index, so the tap machinery is reused instead of a second
+    hook; the rank is computed on the GPU (token Gram in fp64 -> blocked or LDS-resident eigensolver -> device count)."""
+    tokens, _ = extract_intermediates(teacher, images)
+    last = tokens[max(tokens)]
+    return marchenko_pastur_rank(last.reshape(-1, last.shape[-1]).float())
 
 
 @torch.no_grad()
@@ -167,6 +168,8 @@ def extract_intermediates(teacher: TeacherModel, x: torch.Tensor, on_layer=None)
     enqueued (the trainer launches that layer's selector statistics on another stream from it)."""
     x = x.to(next(teacher.model.parameters()).dtype)
     if teacher.feature_format != "token":
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
         feats = _to_token_format(teacher.model.forward_features(x), teacher.feature_format, teacher.has_cls_token)
         b, n, _ = feats.shape
         return {0: feats.contiguous()}, {0: torch.full((b, n), 1.0 / n, device=feats.device)}
