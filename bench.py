@@ -33,12 +33,15 @@ CFG = os.path.join(ROOT, "vit-bias-aware-structural-distillation_amd", "configs"
 
 # BASELINE.json configs: (student preset, teacher preset, image size, student patch, per-GPU batch,
 # fwd FLOPs per image of student / teacher (2*MAC), description).  c2 is the configuration the metric is
-# quoted on and the default; the others are run with --config (c3, the CNN teacher, has its own driver flag).
+# quoted on and the default; the others are run with --config.
 CONFIGS = {
     "c1": ("deit_tiny_patch16_224", "vit_small_patch16_224", 32, 4, 64, 0.73e9, 2.84e9,
            "BASELINE configs[0]: DeiT-Tiny student, ViT-Small teacher, 32x32 images, patch 4"),
     "c2": ("deit_tiny_patch16_224", "vit_base_patch16_224", 224, 16, 256, 2.51e9, 35.13e9,
            "BASELINE configs[1]: DeiT-Tiny/16 student, ViT-Base/16 teacher"),
+    "c3": ("deit_tiny_patch16_224", "resnet50", 224, 16, 256, 2.51e9, 8.2e9,
+           "BASELINE configs[2]: DeiT-Tiny/16 student, ResNet-50 teacher (one layer of 49 tokens x 2048 channels, uniform "
+           "importance; the frozen conv trunk runs through MIOpen as a black box)"),
     "c4": ("deit_small_patch16_224", "vit_large_patch16_224", 224, 16, 128, 9.20e9, 123.1e9,
            "BASELINE configs[3]: DeiT-Small/16 student, ViT-Large/16 teacher (128 images per GPU of the global 1024)"),
     "c5": ("vit_base_patch16_224", "vit_huge_patch14_224", 224, 16, 256, 35.13e9, 334.6e9,
