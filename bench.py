@@ -131,7 +131,13 @@ def main():
                                   f"model.vit.img_size={img_size}", f"model.vit.patch_size={patch}",
                                   f"model.grad_checkpointing={'true' if args.grad_checkpointing else 'false'}"]
                       + ([f"basd.teacher_patch_size={patch}"] if args.config == "c1" else []))
+    def progress(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
     trainer, info = build(cfg, device=dev)
+    progress(f"built {args.config}: {student_preset} / {teacher_preset}, {args.batch} images per GPU")
     loader = SyntheticLoader(args.batch, cfg.model.vit.img_size, cfg.model.num_classes, 1, dev, seed=1234 + rank)
     batch = next(iter(loader))
     trainer.optimizer.train()
@@ -147,6 +153,8 @@ def main():
     timer.active = True
     for i in range(eager_probe):
         loss, _ = trainer.train_step(batch)
+        torch.cuda.synchronize()
+        progress(f"eager step {i}: loss {float(loss):.4f}")
         if i == 0:
             timer.active = False
             ranks = trainer.basd_loss.layer_selector.subspace_ranks
@@ -162,8 +170,11 @@ def main():
     graphed = False
     if not args.eager:
         graphed = trainer.enable_graph(batch)
+        progress(f"hipGraph capture: {'ok' if graphed else 'failed: ' + str(trainer.graph_error)}")
     for i in range(args.warmup):
         loss, _ = trainer.train_step(batch)
+    torch.cuda.synchronize()
+    progress(f"{args.warmup} warm-up steps done; timing {args.steps} steps")
 
     def barrier():
         if world > 1:

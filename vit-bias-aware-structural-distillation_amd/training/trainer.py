@@ -81,7 +81,18 @@ class Trainer:
         self.use_mixup = True
         self.autocast_dtype = torch.bfloat16
         self.overlap_teacher_stats = True
-        self.overlap_teacher_forward = os.environ.get("BASD_OVERLAP_TEACHER", "1") == "1"
+        # Teacher forward next to the student forward (two streams of library GEMMs): measured -2.6 ms/step at the
+        # DeiT-T / ViT-B configuration, but at ViT-B / ViT-H shapes (BASELINE c5, 256 images) the two branches DEADLOCK on
+        # the GPU -- the library's persistent GEMM kernels spin on peers that are never scheduled once both grids
+        # compete for the CUs (reproduced three times; serialised launches or a single GEMM stream run fine).  So the
+        # overlap is on only for the narrow configuration it was validated on, unless basd.overlap_teacher_forward /
+        # BASD_OVERLAP_TEACHER force it either way; the teacher STATISTICS (hand-written kernels) still run on the side
+        # stream.
+        forced = config.basd.get("overlap_teacher_forward", os.environ.get("BASD_OVERLAP_TEACHER"))
+        if forced is None or str(forced).lower() == "auto":
+            self.overlap_teacher_forward = student_info["embed_dim"] <= 192 and teacher.embed_dim <= 768
+        else:
+            self.overlap_teacher_forward = str(forced).lower() in ("1", "true")
         self._side = None
         self._graph = None
         self.graph_error = None
