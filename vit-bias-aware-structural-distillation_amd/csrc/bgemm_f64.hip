@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void bgemm_f64_kernel(const TA* __restrict__ a
 
 
 // ---------------------------------------------------------------------------------------------
-// Pipelined variant for aligned shapes (M, N multiples of 64; K, leading dimensions and batch
-// strides multiples of 4; 32-byte aligned bases) -- every product of the Procrustes core.
+// Pipelined variant for aligned shapes (M, N, K, leading dimensions and batch strides multiples
+// of 4; 32-byte aligned bases; ragged 64-tiles at the M / N edges read zeros) -- every product of
+// the Procrustes core, including the 196-token Gram matrices.
 // The kernel above stages element-wise with bounds checks (98 VGPRs + 32 AGPRs: 3-4 waves per
 // SIMD) and waits for its global loads between two barriers per K chunk: 46-58 % of the measured
 // 47 TFLOP/s fp64-MFMA ceiling.  Here each thread fetches one 4-element vector of A and of B for
@@ -120,14 +121,17 @@ template <> struct Vec4<double> { typedef double type __attribute__((ext_vector_
 // KMAJ == 1: the operand tile is contiguous along the tile dimension  -> element (k, i) = x[(k0 + k) * ld + t0 + i]
 // KMAJ == 0: the operand tile is contiguous along k                  -> element (k, i) = x[(t0 + i) * ld + k0 + k]
 template <typename T, int KMAJ>
-__device__ __forceinline__ typename Vec4<T>::type fetch4(const T* __restrict__ x, int ld, int t0, int k0, int K, int tid) {
+__device__ __forceinline__ typename Vec4<T>::type fetch4(const T* __restrict__ x, int ld, int t0, int tdim, int k0, int K,
+                                                         int tid) {
   typedef typename Vec4<T>::type V;
+  // tdim and K are multiples of 4: a 4-vector is entirely inside or entirely outside the matrix (ragged edge tiles
+  // of e.g. the 196-token Gram matrices read zeros there)
   if (KMAJ) {
     const int k = tid >> 4, i4 = (tid & 15) * 4;
-    if (k0 + k < K) return *reinterpret_cast<const V*>(x + (size_t)(k0 + k) * ld + t0 + i4);
+    if (k0 + k < K && t0 + i4 < tdim) return *reinterpret_cast<const V*>(x + (size_t)(k0 + k) * ld + t0 + i4);
   } else {
     const int i = tid >> 2, kq = (tid & 3) * 4;
-    if (k0 + kq < K) return *reinterpret_cast<const V*>(x + (size_t)(t0 + i) * ld + k0 + kq);
+    if (k0 + kq < K && t0 + i < tdim) return *reinterpret_cast<const V*>(x + (size_t)(t0 + i) * ld + k0 + kq);
   }
   return (V){0, 0, 0, 0};
 }
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
     for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
   // op(A) tile: TRA == 0 -> A is [M, K] (contiguous along k); TRA == 1 -> A is [K, M]
   // op(B) tile: TRB == 0 -> B is [K, N] (contiguous along the tile dim); TRB == 1 -> B is [N, K]
-  typename Vec4<TA>::type ra = fetch4<TA, TRA>(A, lda, m0, 0, K, tid);
-  typename Vec4<TB>::type rb = fetch4<TB, 1 - TRB>(B, ldb, n0, 0, K, tid);
+  typename Vec4<TA>::type ra = fetch4<TA, TRA>(A, lda, m0, M, 0, K, tid);
+  typename Vec4<TB>::type rb = fetch4<TB, 1 - TRB>(B, ldb, n0, N, 0, K, tid);
   park4<TA, TRA>(ra, As[0], tid);
   park4<TB, 1 - TRB>(rb, Bs[0], tid);
   __syncthreads();
@@ -178,8 +182,8 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
     const int cur = ch & 1;
     const bool more = ch + 1 < nchunk;
     if (more) {
-      ra = fetch4<TA, TRA>(A, lda, m0, (ch + 1) * BK, K, tid);
-      rb = fetch4<TB, 1 - TRB>(B, ldb, n0, (ch + 1) * BK, K, tid);
+      ra = fetch4<TA, TRA>(A, lda, m0, M, (ch + 1) * BK, K, tid);
+      rb = fetch4<TB, 1 - TRB>(B, ldb, n0, N, (ch + 1) * BK, K, tid);
     }
     const double* as = As[cur];
     const double* bs = Bs[cur];
@@ -211,15 +215,17 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
       for (int reg = 0; reg < 4; ++reg) {
         const int r = m0 + wm + i * 16 + (lane >> 4) + 4 * reg;
         const int col = n0 + wn + j * 16 + (lane & 15);
-        C[(size_t)r * ldc + col] = (TC)acc[i][j][reg];
-        if (sym && n0 != m0) C[(size_t)col * ldc + r] = (TC)acc[i][j][reg];
+        if (r < M && col < N) {
+          C[(size_t)r * ldc + col] = (TC)acc[i][j][reg];
+          if (sym && n0 != m0) C[(size_t)col * ldc + r] = (TC)acc[i][j][reg];
+        }
       }
 }
 
 template <typename TA, typename TB, typename TC>
 static void launch_bgemm_fast(const void* a, int64_t sa, int lda, int ta, const void* b, int64_t sb, int ldb, int tb,
                               void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, hipStream_t st) {
-  dim3 grid(N / BT, M / BT, batch);
+  dim3 grid((N + BT - 1) / BT, (M + BT - 1) / BT, batch);
 #define BASD_BGF(TRA, TRB)                                                                                   \
   hipLaunchKernelGGL((bgemm_f64_fast_kernel<TA, TB, TC, TRA, TRB>), grid, dim3(256), 0, st, (const TA*)a, sa, lda, \
                      (const TB*)b, sb, ldb, (TC*)c, sc, ldc, M, N, K, sym)
@@ -247,7 +253,7 @@ extern "C" int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int 
   if (K <= 0 || batch > 65535) return fail(BASD_ERR_SHAPE, "bgemm_f64: bad shape batch=%d K=%d", batch, K);
   hipStream_t st = (hipStream_t)stream;
   const int key = a_dtype * 100 + b_dtype * 10 + c_dtype;
-  const bool aligned = M % BT == 0 && N % BT == 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+  const bool aligned = M % 4 == 0 && N % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
                        a_stride % 4 == 0 && b_stride % 4 == 0 && ((uintptr_t)a & 31) == 0 && ((uintptr_t)b & 31) == 0;
 #define BASD_BG(TA, TB, TC)                                                                                          \
   do {                                                                                                               \

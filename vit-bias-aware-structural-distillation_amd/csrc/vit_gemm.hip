@@ -40,7 +40,7 @@ template <int KT>   // k tiles of 16 per workgroup: TK = 16 * KT
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const unsigned short* __restrict__ dy,
                                                          const unsigned short* __restrict__ x, int64_t M, int N,
                                                          int K, float* __restrict__ dw, float* __restrict__ db,
-                                                         int64_t rows_per_slice) {
+                                                         int64_t rows_per_slice, int tn, int tk, int slices) {
   constexpr int TK = 16 * KT;
   constexpr int X_LD = TK + 8;                       // LDS row stride of the X chunk, in bf16
   constexpr int DY_VEC = WG_MC * WG_TN / 8 / 256;    // uint4 loads per thread (2)
@@ -48,8 +48,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const unsigned short* _
   __shared__ __align__(16) unsigned short dYs[WG_MC * DY_LD];
   __shared__ __align__(16) unsigned short Xs[WG_MC * X_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * WG_TN, k0 = blockIdx.y * TK;
-  const int64_t m_begin = (int64_t)blockIdx.z * rows_per_slice;
+  // XCD-aware 1-D grid: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the tn * tk tiles
+  // that re-read ONE M-slab of X / dY must share blockIdx.x % 8 to hit the same L2.  Linear id = ((slice / 8) * tiles
+  // + tile) * 8 + slice % 8: the tiles of a slab are also adjacent in dispatch order.  (With the natural (n, k, slice)
+  // grid the 12 n-tiles of a slab sat on different XCDs and every one fetched it again: 3x the algorithmic HBM bytes.)
+  const int tiles = tn * tk;
+  const int lin = blockIdx.x;
+  const int slice = (lin / (8 * tiles)) * 8 + (lin & 7);
+  if (slice >= slices) return;
+  const int tile = (lin >> 3) % tiles;
+  const int bx = tile % tn, by = tile / tn;
+  const int n0 = bx * WG_TN, k0 = by * TK;
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
   int64_t m_end = m_begin + rows_per_slice;
   if (m_end > M) m_end = M;
 
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const unsigned short* _
 #pragma unroll
     for (int t = 0; t < KW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const bool do_bias = (db != nullptr) && (blockIdx.y == 0);
+  const bool do_bias = (db != nullptr) && (by == 0);
 
   uint4 rdy[DY_VEC], rx[X_VEC];
   auto load_chunk = [&](int64_t m0) {
@@ -150,8 +160,9 @@ static void launch_wgrad(const void* dy, const void* x, int64_t M, int N, int K,
   int64_t rps = (M + slices - 1) / slices;
   rps = (rps + WG_MC - 1) / WG_MC * WG_MC;
   slices = (M + rps - 1) / rps;
-  hipLaunchKernelGGL((wgrad_bf16_kernel<KT>), dim3(tn, tk, (int)slices), dim3(256), 0, st,
-                     (const unsigned short*)dy, (const unsigned short*)x, M, N, K, dw, db, rps);
+  const int groups = (int)((slices + 7) / 8);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<KT>), dim3(groups * tn * tk * 8), dim3(256), 0, st,
+                     (const unsigned short*)dy, (const unsigned short*)x, M, N, K, dw, db, rps, tn, tk, (int)slices);
 }
 
 }  // namespace basd

@@ -374,37 +374,47 @@ def mix_layers(w: torch.Tensor, layers) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # Procrustes
 # --------------------------------------------------------------------------- #
-def _polar_core(cross: torch.Tensor):
-    """cross [B, r, c] fp64 with r <= 196 -> (sigma [B, r] fp32, m [B, r, r] fp64) with polar(cross) = U V^T = m @ cross.
+def _polar_core_gram(mx: torch.Tensor):
+    """mx = X X^T [B, r, r] fp64 (lower triangle meaningful) of some X [B, r, c] with r <= 196 ->
+    (sigma [B, r] fp32 = singular values of X, m [B, r, r] fp64) with polar(X) = U V^T = m @ X.
 
-    The Gram cross cross^T is formed in fp64; its pivoted Cholesky factor L (cross = L Q2, Q2 = L^-1 cross with
-    orthonormal rows) is diagonalised by the fp32 Jacobi: L J1 = U Sigma.  The right factor J1 = L^-1 (U Sigma) uses
-    the explicit fp64 inverse of the graded L (never a division by sigma), so (U, J1) is a consistent pair and
-    U V^T = U J1^T Q2 = (U J1^T L^-1) cross is orthonormal to working precision.
+    The pivoted Cholesky factor L of the Gram (X = L Q2, Q2 = L^-1 X with orthonormal rows) is diagonalised by the
+    fp32 Jacobi: L J1 = U Sigma.  The right factor J1 = L^-1 (U Sigma) uses the explicit fp64 inverse of the graded L
+    (never a division by sigma), so (U, J1) is a consistent pair and U V^T = U J1^T Q2 = (U J1^T L^-1) X is
+    orthonormal to working precision.
     """
     ops = get_ops()
-    r = cross.shape[1]
-    mx = ops.bgemm_f64(cross, cross, trans_b=True, symmetric=True)     # exactly symmetric by construction
+    r = mx.shape[1]
     w0, lwork, piv, rank = ops.pchol(mx, PCHOL_TOL)
     sigma, _ = ops.jacobi_svd(w0, r)                                    # w0[:, i, :r] = sigma_i u_i
     l_inv = ops.trinv(lwork, piv, rank)                                 # L_p^-1 P  [B, k, r] fp64
     wf = w0[:, :, :r].contiguous()                                      # [B, i, r] = sigma_i u_i[r]
     j1 = ops.bgemm_f64(l_inv, wf, trans_b=True)                         # [B, k, i]:  L J1 = U Sigma
     u = torch.where(sigma.unsqueeze(-1) > 0, wf / sigma.clamp_min(1e-30).unsqueeze(-1),
-                    torch.zeros(1, device=cross.device))                # [B, i, r]
+                    torch.zeros(1, device=mx.device))                   # [B, i, r]
     theta = ops.bgemm_f64(u, j1, trans_a=True, trans_b=True)            # [B, r, k] = polar(L), fp64
-    # polar(cross) = theta Q2 with Q2 = L^-1 cross: associate as (theta L^-1) cross so that the [k, c] factor is
-    # never rounded to fp32 (all on the fp64 MFMA)
+    # polar(X) = theta Q2 with Q2 = L^-1 X: associate as (theta L^-1) X so that the [k, c] factor is never rounded
+    # to fp32 (all on the fp64 MFMA)
     return sigma, ops.bgemm_f64(theta, l_inv)                           # [B, r, r'] fp64
 
 
-def _polar_of_cross(s_w: torch.Tensor, t_w: torch.Tensor):
-    """Feature-side form (D_s <= 192 <= N_s - 1, e.g. BASELINE c2): nuclear norm [B] and polar factor
-    G = U V^T [B, D_s, D_t] fp32 of cross = s_w^T t_w (formed in fp64)."""
+def _polar_feature_side(s_w: torch.Tensor, t_w: torch.Tensor):
+    """Feature-side form (D_s <= 192 <= N_s - 1, e.g. BASELINE c2): nuclear norm [B] of cross = s_w^T t_w and the two
+    factors of the backward,  t_w G^T = p_s [B, N, D_s]  and  s_w G = a_t t_w  (a_t [B, N, N]),  G = U V^T = m cross.
+
+    cross [D_s, D_t] itself is never formed: with G_t = t_w t_w^T (N x N, ONE pass over t_w, fp64)
+        cross cross^T = s_w^T G_t s_w,   t_w G^T = G_t (m s_w^T)^T,   s_w G = (s_w m s_w^T) t_w,
+    all N x N / N x D_s products.  (Round 1 materialised cross in fp64 -- 1.2 GB at c2 -- and streamed it three
+    times, then wrote G in fp32: 8 GB of algorithmic traffic, 18.5 GB counted; this form moves the 0.6 GB of t_w
+    once here and once in the backward.)"""
     ops = get_ops()
-    cross = ops.bgemm_f64(s_w, t_w, trans_a=True)                       # [B, D_s, D_t] fp64
-    sigma, m = _polar_core(cross)
-    return sigma.sum(dim=-1), ops.bgemm_f64(m, cross, out_dtype=torch.float32)
+    gt = ops.bgemm_f64(t_w, t_w, trans_b=True, symmetric=True)          # [B, N, N] fp64
+    h = ops.bgemm_f64(gt, s_w)                                          # [B, N, D_s] fp64
+    sigma, m = _polar_core_gram(ops.bgemm_f64(s_w, h, trans_a=True))    # Gram of cross, [B, D_s, D_s]
+    p = ops.bgemm_f64(m, s_w, trans_b=True)                             # m s_w^T  [B, D_s, N] fp64
+    p_s = ops.bgemm_f64(gt, p, trans_b=True, out_dtype=torch.float32)   # G_t P^T = t_w G^T  [B, N, D_s]
+    a_t = ops.bgemm_f64(s_w, p, out_dtype=torch.float32)                # s_w P  [B, N, N]
+    return sigma.sum(dim=-1), p_s, a_t
 
 
 def _polar_token_side(s_w: torch.Tensor, t_w: torch.Tensor):
@@ -426,7 +436,7 @@ def _polar_token_side(s_w: torch.Tensor, t_w: torch.Tensor):
     w_s = ops.trinv(r_s, piv_s, rk_s)                                    # [B, k, n]
     w_t = ops.trinv(r_t, piv_t, rk_t)
     core = ops.bgemm_f64(r_s, r_t, trans_b=True)                         # C [B, k_s, k_t] fp64
-    sigma, m = _polar_core(core)
+    sigma, m = _polar_core_gram(ops.bgemm_f64(core, core, trans_b=True, symmetric=True))
     pc = ops.bgemm_f64(m, core)                                          # polar(C) [B, k_s, k_t] fp64
     a_s = ops.bgemm_f64(ops.bgemm_f64(pc, r_t), w_s, trans_a=True, out_dtype=torch.float32)    # (pc R_t)^T W_s
     a_t = ops.bgemm_f64(ops.bgemm_f64(r_s, pc, trans_a=True), w_t, out_dtype=torch.float32)    # (R_s^T pc) W_t
@@ -458,8 +468,8 @@ class _ProcrustesFn(torch.autograd.Function):
             nuc, a_s, a_t = _polar_token_side(s_w, t_w)
             ctx.save_for_backward(s_w, t_w, a, imp_all, a_s, a_t)
         else:
-            nuc, g = _polar_of_cross(s_w, t_w)
-            ctx.save_for_backward(s_w, t_w, a, imp_all, g)
+            nuc, p_s, a_t = _polar_feature_side(s_w, t_w)
+            ctx.save_for_backward(s_w, t_w, a, imp_all, p_s, a_t)
         ctx.n_t, ctx.E = n_t, E
         ctx.s_dtype = students[0].dtype
         return (tr[:, 0] + tr[:, 1] - 2.0 * nuc).view(E, -1)
@@ -476,7 +486,10 @@ class _ProcrustesFn(torch.autograd.Function):
         if ctx.token_side:
             p_s, p_t = polar[0] @ s_w, polar[1] @ t_w                # t_w G^T = A_s s_w, s_w G = A_t t_w
         else:
-            p_s, p_t = t_w @ polar[0].transpose(1, 2), s_w @ polar[0]
+            # t_w G^T was formed in the forward (the fp32 row kernel below works in place: keep the saved copy
+            # intact for a second backward); s_w G = A_t t_w
+            p_s = polar[0].clone() if ctx.s_dtype == torch.float32 else polar[0]
+            p_t = polar[1] @ t_w
         g_s, dot_s = ops.procrustes_bwd_rows(p_s, s_w, a, gl, out_dtype=ctx.s_dtype)
         g_t, dot_t = ops.procrustes_bwd_rows(p_t, t_w, a, gl, out_dtype=torch.float32)
         g_a = (dot_s + dot_t) / (2.0 * a)
