@@ -22,6 +22,7 @@
  *   basd_mix_tokens        layer_selector.py:110-112 (+ torch.stack :128-129 eliminated)
  *   basd_procrustes_prep   src/losses/relational.py:29-46, src/losses/combined.py:9-14
  *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
+ *   basd_gemm_bf16         timm nn.Linear (+ nn.GELU) forward of the ViT blocks, teacher.py:212 / trainer.py:33
  *   basd_wgrad_bf16        autograd of the student's timm nn.Linear layers (trainer.py:157)
  *   basd_sf_adamw_step     schedulefree.AdamWScheduleFree.step  src/training/trainer.py:54-58,158
  *   basd_bgemm_f64, basd_trinv_f64
@@ -177,6 +178,14 @@ int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int tr
                    const void* b, int b_dtype, int64_t b_stride, int ldb, int trans_b,
                    void* c, int c_dtype, int64_t c_stride, int ldc,
                    int batch, int M, int N, int K, int symmetric, void* stream);
+
+/* ViT linear layer on the bf16 matrix cores with a fused epilogue (timm nn.Linear + nn.GELU of the blocks; reference
+ * call sites src/models/teacher.py:212 and src/training/trainer.py:33; with w := W^T also the input gradient
+ * dX = dY W of trainer.py:157):   y[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]),
+ * x [M, K], w [N, K], y [M, N], bias [N] (nullable) all bf16 row-major, fp32 accumulation.
+ * epilogue: 0 = none, 1 = + bias, 2 = exact-erf GELU(+ bias).  K % 64 == 0, N a multiple of 256, 192 or 128. */
+int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
+                   int epilogue, void* stream);
 
 /* ViT weight-gradient GEMM (backward of nn.Linear): dw[n][k] += sum_m dy[m][n] x[m][k],
  * db[n] += sum_m dy[m][n] (db may be NULL).  dy [M, N], x [M, K] bf16 row-major, dw [N, K] /

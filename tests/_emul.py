@@ -228,6 +228,19 @@ def trinv(lwork, piv, rank):
     return out
 
 
+def gemm_supported(n, k):
+    return k % 64 == 0 and k >= 64 and n >= 128 and (n % 256 == 0 or n % 192 == 0 or n % 128 == 0)
+
+
+def gemm_bf16(x, w, bias=None, gelu=False):
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    if gelu:
+        y = torch.nn.functional.gelu(y)
+    return y.to(torch.bfloat16)
+
+
 def wgrad_supported(n, k):
     return n % 64 == 0 and k % 64 == 0 and n >= 64 and k >= 64
 

@@ -339,6 +339,34 @@ def test_jacobi_active_block_matches_full_run(nat):
         assert float(s2[b, k:].abs().max()) == 0.0 if k < n else True
 
 
+@pytest.mark.parametrize("M,N,K,gelu,bias", [(50432, 3072, 768, True, True), (50432, 768, 3072, False, True),
+                                            (50432, 576, 192, False, True), (50432, 192, 768, False, False),
+                                            (25216, 384, 1536, False, True), (1000, 768, 768, False, True),
+                                            (300, 128, 64, True, True), (517, 1280, 320, True, False)])
+def test_gemm_bf16_with_fused_epilogue(nat, M, N, K, gelu, bias):
+    """basd_gemm_bf16 (ring kernel for 256-wide tiles, two-stage kernel for 192 / 128; ragged M; bias / exact-erf GELU
+    epilogue) against the fp32 product of the SAME bf16 inputs: the only difference allowed is the final bf16
+    rounding (2^-8 relative) plus the fp32 accumulation order"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda() if bias else None
+    y = nat.gemm_bf16(x, w, b, gelu=gelu)
+    ref = x.float() @ w.float().t()
+    if b is not None:
+        ref = ref + b.float()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    assert y.dtype == torch.bfloat16 and y.shape == (M, N)
+    err = (y.float() - ref).abs()
+    assert float((err / (ref.abs() + 1e-2 * float(ref.abs().max()))).max()) < 1.2e-2
+    assert float(err.max()) <= 6e-3 * float(ref.abs().max())
+    # batched input view [B, T, K] -> [B, T, N]
+    if M % 4 == 0:
+        y3 = nat.gemm_bf16(x.view(4, M // 4, K), w, b, gelu=gelu)
+        assert y3.shape == (4, M // 4, N) and torch.equal(y3.reshape(M, N), y)
+
+
 @pytest.mark.parametrize("M,N,K", [(50432, 576, 192), (1000, 192, 768), (333, 64, 64), (4096, 768, 192), (777, 128, 128)])
 def test_wgrad_bf16(nat, M, N, K):
     g = torch.Generator().manual_seed(M + N)

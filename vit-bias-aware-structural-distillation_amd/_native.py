@@ -21,7 +21,7 @@ JACOBI_LDS_BYTES = 163840
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
-    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
+    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_gemm_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16",
 )
 
@@ -42,6 +42,7 @@ _SIGNATURES = {
     "basd_mix_grad_dots": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
     "basd_bgemm_f64": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P),
     "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
+    "basd_gemm_bf16": (_P, _P, _P, _P, _I64, _I, _I, _I, _P),
     "basd_layernorm_fwd_bf16": (_P, _P, _P, _I64, _I, _F, _P, _P, _P, _P),
     "basd_add_layernorm_fwd_bf16": (_P, _P, _P, _P, _I64, _I, _F, _P, _P, _P, _P, _P),
     "basd_layernorm_bwd_bf16": (_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P),
@@ -454,6 +455,29 @@ def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor) -> torch.T
     _check(lib().basd_trinv_f64(_ptr(lwork.contiguous()), _ptr(piv.contiguous()), _ptr(rank.contiguous()), batch, n,
                                 _ptr(out), _stream()), "basd_trinv_f64")
     return out
+
+
+def gemm_supported(n: int, k: int) -> bool:
+    return k % 64 == 0 and k >= 64 and n >= 128 and (n % 256 == 0 or n % 192 == 0 or n % 128 == 0)
+
+
+def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, gelu: bool = False) -> torch.Tensor:
+    """x [..., K], w [N, K], bias [N] | None (all bf16) -> epi(x w^T + bias) [..., N] bf16; epi = exact-erf GELU if
+    ``gelu``.  Inference / explicit-backward building block (no autograd)."""
+    _need_cuda(x, w, bias)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.bfloat16)
+    k = x.shape[-1]
+    n = w.shape[0]
+    assert w.shape[1] == k and gemm_supported(n, k), (tuple(w.shape), k)
+    x2 = x.reshape(-1, k)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    w = w.contiguous()
+    y = torch.empty(x2.shape[0], n, dtype=torch.bfloat16, device=x.device)
+    epi = 2 if gelu else (1 if bias is not None else 0)
+    _check(lib().basd_gemm_bf16(_ptr(x2), _ptr(w), _ptr(None if bias is None else bias.contiguous()), _ptr(y),
+                                ctypes.c_int64(x2.shape[0]), n, k, epi, _stream()), "basd_gemm_bf16")
+    return y.view(*x.shape[:-1], n)
 
 
 def wgrad_supported(n: int, k: int) -> bool:

@@ -223,6 +223,8 @@ class Mlp(nn.Module):
         self.fc2 = BasdLinear(hidden, dim)
 
     def forward(self, x):
+        if self.fc1.fused_inference_ok(x):        # frozen block: exact-erf GELU in the epilogue of the fc1 GEMM
+            return self.fc2(get_ops().gemm_bf16(x, self.fc1.weight, self.fc1.bias, gelu=True))
         return self.fc2(self.act(self.fc1(x)))
 
 
