@@ -30,6 +30,8 @@
  *                          (torch.linalg.svd backward -> U V^T), formed in fp64
  *   basd_procrustes_bwd_rows
  *                          autograd of relational.py:29-46 (centring, sqrt-weights, traces)
+ *   basd_attention_bwd_bf16
+ *                          autograd through timm Attention.forward of the student (trainer.py:157)
  *   basd_attention_fwd_bf16, basd_cls_importance_bf16
  *                          timm Attention.forward of the frozen teacher (teacher.py:118 creates it) and the
  *                          attention capture hook src/models/teacher.py:27-39 + relational.py:22-27
@@ -226,9 +228,18 @@ int basd_cls_importance_bf16(const void* qkv, int B, int T, int H, int hd, float
  * out [B, T, H * hd] bf16 = softmax(Q K^T * scale) V per head (fp32 logits / probabilities, P rounded to bf16
  * for the second product, like the library flash kernel it replaces on the teacher: torch SDPA called at
  * timm Attention.forward).  importance (nullable): [B, H, T-1] fp32; receives per head the CLS-row softmax of
- * basd_cls_importance_bf16 divided by H (the tap is the sum over the H axis).  hd == 64, T <= 272. */
+ * basd_cls_importance_bf16 divided by H (the tap is the sum over the H axis).  lse (nullable): [B, H, T] fp32,
+ * log-sum-exp of the scaled logits per query (input of basd_attention_bwd_bf16).  hd == 64, T <= 272. */
 int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int hd, float scale, void* out,
-                            float* importance, void* stream);
+                            float* importance, float* lse, void* stream);
+
+/* Fused attention backward of a trained block (the student; reference src/training/trainer.py:157 through timm
+ * Attention.forward): qkv [B, T, 3, H, hd] bf16, out / dout [B, T, H * hd] bf16 (forward output and its gradient),
+ * lse [B, H, T] fp32 from basd_attention_fwd_bf16 -> dqkv [B, T, 3, H, hd] bf16, the gradient of the packed
+ * projection.  P is recomputed (nothing T x T is stored); fp32 accumulation, P and dS rounded to bf16 for the second
+ * products like a flash kernel.  hd == 64, T <= 224. */
+int basd_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int T, int H,
+                            int hd, float scale, void* dqkv, void* stream);
 
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:

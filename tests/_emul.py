@@ -280,14 +280,32 @@ def attention_fwd_supported(t, hd):
     return hd == 64 and 1 <= t <= 272
 
 
-def attention_fwd(qkv, heads, head_dim, scale, want_importance=False):
+def attention_fwd(qkv, heads, head_dim, scale, want_importance=False, want_lse=False):
     b, t, _ = qkv.shape
     x = qkv.reshape(b, t, 3, heads, head_dim).permute(2, 0, 3, 1, 4).float()
     q, k, v = x[0], x[1], x[2]
-    p = ((q @ k.transpose(-1, -2)) * scale).softmax(dim=-1)
+    logits = (q @ k.transpose(-1, -2)) * scale
+    p = logits.softmax(dim=-1)
     out = (p.to(torch.bfloat16).float() @ v).transpose(1, 2).reshape(b, t, heads * head_dim).to(torch.bfloat16)
     imp = cls_importance(qkv, heads, head_dim, scale) if want_importance else None
+    if want_lse:
+        return out, imp, torch.logsumexp(logits, dim=-1)
     return out, imp
+
+
+def attention_bwd_supported(t, hd):
+    return hd == 64 and 1 <= t <= 224
+
+
+def attention_bwd(qkv, out, dout, lse, heads, head_dim, scale):
+    b, t, _ = qkv.shape
+    with torch.enable_grad():
+        x = qkv.detach().float().reshape(b, t, 3, heads, head_dim).requires_grad_(True)
+        q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+        p = ((q @ k.transpose(-1, -2)) * scale).softmax(dim=-1)
+        o = (p @ v).transpose(1, 2).reshape(b, t, heads * head_dim)
+        o.backward(dout.float())
+    return x.grad.reshape(b, t, -1).to(torch.bfloat16)
 
 
 def layernorm_supported(d):

@@ -598,6 +598,33 @@ def test_jacobi_converges_on_clustered_spectra(nat, batch):
     assert torch.allclose(sigma[:4].cpu().double(), ref, rtol=2e-5, atol=0)
 
 
+@pytest.mark.parametrize("B,T,H", [(3, 197, 3), (2, 65, 3), (2, 224, 6), (5, 17, 2), (2, 96, 12)])
+def test_attention_bwd_matches_autograd(nat, B, T, H):
+    """fused attention forward (+ LSE) and backward kernels against fp32 autograd through softmax(Q K^T / sqrt(hd)) V
+    on the same bf16 inputs: outputs / gradients differ by the bf16 rounding of P, dS and of the results only"""
+    hd = 64
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B, T, 3 * H * hd, generator=g) * 0.8).bfloat16().cuda()
+    dout = torch.randn(B, T, H * hd, generator=g).bfloat16().cuda()
+    scale = hd ** -0.5
+    out, _, lse = nat.attention_fwd(qkv, H, hd, scale, want_lse=True)
+    dqkv = nat.attention_bwd(qkv, out, dout, lse, H, hd, scale)
+    x = qkv.float().reshape(B, T, 3, H, hd).requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    logits = (q @ k.transpose(-1, -2)) * scale
+    o = (logits.softmax(dim=-1) @ v).transpose(1, 2).reshape(B, T, H * hd)
+    o.backward(dout.float())
+    ref = x.grad.reshape(B, T, -1)
+    assert torch.allclose(lse, torch.logsumexp(logits, dim=-1).detach(), rtol=1e-5, atol=1e-4)
+    assert float((out.float() - o.detach()).abs().max()) < 2e-2
+    parts = dqkv.float().reshape(B, T, 3, H * hd), ref.reshape(B, T, 3, H * hd)
+    for i, name in enumerate("qkv"):
+        got, want = parts[0][:, :, i], parts[1][:, :, i]
+        rel = float((got - want).norm() / want.norm())
+        assert rel < 1.5e-2, (name, rel)
+        assert float((got - want).abs().max()) < 4e-2 * float(want.abs().max()), name
+
+
 def test_empty_batches_are_noops(nat):
     """zero-sized batches return without launching (every C-ABI entry checks for them first)"""
     dev = "cuda"

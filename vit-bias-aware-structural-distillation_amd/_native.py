@@ -22,7 +22,7 @@ EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_gemm_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
-    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16",
+    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
 )
 
 
@@ -48,7 +48,8 @@ _SIGNATURES = {
     "basd_layernorm_bwd_bf16": (_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P),
     "basd_procrustes_bwd_rows": (_P, _P, _P, _P, _I64, _I, _I, _P, _I, _P, _P),
     "basd_cls_importance_bf16": (_P, _I, _I, _I, _I, _F, _P, _P),
-    "basd_attention_fwd_bf16": (_P, _I, _I, _I, _I, _F, _P, _P, _P),
+    "basd_attention_fwd_bf16": (_P, _I, _I, _I, _I, _F, _P, _P, _P, _P),
+    "basd_attention_bwd_bf16": (_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P),
     "basd_sf_adamw_step": (_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _D, _D, _P),
     "basd_lerp": (_P, _P, _I64, _F, _P),
 }
@@ -523,18 +524,40 @@ def attention_fwd_supported(t: int, hd: int) -> bool:
     return hd == 64 and 1 <= t <= 272
 
 
-def attention_fwd(qkv: torch.Tensor, heads: int, head_dim: int, scale: float, want_importance: bool = False):
-    """qkv [B, T, 3 * heads * head_dim] bf16 -> (out [B, T, heads * head_dim] bf16, importance [B, T-1] fp32 | None).
-    Inference only (no autograd)."""
+def attention_fwd(qkv: torch.Tensor, heads: int, head_dim: int, scale: float, want_importance: bool = False,
+                  want_lse: bool = False):
+    """qkv [B, T, 3 * heads * head_dim] bf16 -> (out [B, T, heads * head_dim] bf16, importance [B, T-1] fp32 | None)
+    and, with ``want_lse``, additionally the log-sum-exp [B, heads, T] fp32 the backward kernel needs.  No autograd
+    here (the student wraps forward + ``attention_bwd`` in an autograd.Function)."""
     _need_cuda(qkv)
     assert qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 3 * heads * head_dim
     qkv = qkv.contiguous()
     b, t = qkv.shape[0], qkv.shape[1]
     out = torch.empty(b, t, heads * head_dim, dtype=torch.bfloat16, device=qkv.device)
     imp = torch.empty(b, heads, t - 1, dtype=torch.float32, device=qkv.device) if want_importance else None
+    lse = torch.empty(b, heads, t, dtype=torch.float32, device=qkv.device) if want_lse else None
     _check(lib().basd_attention_fwd_bf16(_ptr(qkv), b, t, heads, head_dim, ctypes.c_float(scale), _ptr(out), _ptr(imp),
-                                         _stream()), "basd_attention_fwd_bf16")
-    return out, (imp.sum(dim=1) if want_importance else None)
+                                         _ptr(lse), _stream()), "basd_attention_fwd_bf16")
+    imp = imp.sum(dim=1) if want_importance else None
+    return (out, imp, lse) if want_lse else (out, imp)
+
+
+def attention_bwd_supported(t: int, hd: int) -> bool:
+    return hd == 64 and 1 <= t <= 224
+
+
+def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, heads: int,
+                  head_dim: int, scale: float) -> torch.Tensor:
+    """-> dqkv [B, T, 3 * heads * head_dim] bf16 (gradient of the packed projection)."""
+    _need_cuda(qkv, out, dout, lse)
+    b, t = qkv.shape[0], qkv.shape[1]
+    assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and lse.dtype == torch.float32
+    assert qkv.is_contiguous() and out.is_contiguous() and lse.is_contiguous() and lse.shape == (b, heads, t)
+    dout = dout.to(torch.bfloat16).contiguous()
+    dqkv = torch.empty_like(qkv)
+    _check(lib().basd_attention_bwd_bf16(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), b, t, heads, head_dim,
+                                         ctypes.c_float(scale), _ptr(dqkv), _stream()), "basd_attention_bwd_bf16")
+    return dqkv
 
 
 def layernorm_supported(d: int) -> bool:

@@ -1,4 +1,5 @@
-// Fused attention forward for the frozen teacher blocks (inference): out = softmax(Q K^T / sqrt(hd)) V
+// Fused attention forward (frozen teacher blocks, and the student with the LSE output for basd_attention_bwd_bf16):
+// out = softmax(Q K^T / sqrt(hd)) V
 // straight from the packed qkv projection [B, T, 3, H, hd] (bf16) into [B, T, H * hd] (bf16) -- the
 // layout the output projection reads -- plus, optionally, the attention tap the distillation loss
 // consumes, per head: importance[b, h, t-1] = softmax_t(bf16(q_cls . k_t) * scale) / H  (summed over h by the
@@ -46,7 +47,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 template <int NKT>   // key tiles of 16: T <= 16 * NKT
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int T, int H,
                                                             float scale, unsigned short* __restrict__ out,
-                                                            float* __restrict__ importance) {
+                                                            float* __restrict__ importance, float* __restrict__ lse) {
   constexpr int NKS = (NKT + 1) / 2;                 // 32-key steps of the P V product
   constexpr int KROWS = 32 * NKS;                    // LDS rows (zero padded)
   extern __shared__ __align__(16) unsigned short sm[];
@@ -185,6 +186,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
+    // log-sum-exp of the scaled logits (natural log): what the backward kernel recomputes P from
+    if (lse != nullptr && g == 0 && q0 + li < T) lse[((size_t)b * H + h) * T + q0 + li] = fmaf(mx, scale, __logf(sum));
     // ---- O = P V
     at_f32x4 o[4];
 #pragma unroll
@@ -234,26 +237,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int NKT>
 static void launch_attention(const void* qkv, int B, int T, int H, float scale, void* out, float* importance,
-                             hipStream_t st) {
+                             float* lse, hipStream_t st) {
   constexpr int KROWS = 32 * ((NKT + 1) / 2);
   const size_t lds = ((size_t)2 * KROWS * AT_LD + 4 * 16 * AT_LD) * sizeof(unsigned short);
   allow_full_lds((const void*)attention_fwd_kernel<NKT>);
   hipLaunchKernelGGL(attention_fwd_kernel<NKT>, dim3(B * H), dim3(256), lds, st, (const unsigned short*)qkv, T, H, scale,
-                     (unsigned short*)out, importance);
+                     (unsigned short*)out, importance, lse);
 }
 
 }  // namespace basd
 
 extern "C" int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int hd, float scale, void* out,
-                                       float* importance, void* stream) {
+                                       float* importance, float* lse, void* stream) {
   using namespace basd;
   if (B <= 0) return BASD_OK;
   if (hd != AT_HD || T < 1 || T > 272 || H < 1)
     return fail(BASD_ERR_SHAPE, "attention_fwd: T=%d H=%d hd=%d unsupported (hd 64, T <= 272)", T, H, hd);
   if (importance != nullptr && T < 2) return fail(BASD_ERR_SHAPE, "attention_fwd: importance needs T >= 2");
   hipStream_t st = (hipStream_t)stream;
-  if (T <= 64) launch_attention<4>(qkv, B, T, H, scale, out, importance, st);
-  else if (T <= 208) launch_attention<13>(qkv, B, T, H, scale, out, importance, st);
-  else launch_attention<17>(qkv, B, T, H, scale, out, importance, st);
+  if (T <= 64) launch_attention<4>(qkv, B, T, H, scale, out, importance, lse, st);
+  else if (T <= 208) launch_attention<13>(qkv, B, T, H, scale, out, importance, lse, st);
+  else launch_attention<17>(qkv, B, T, H, scale, out, importance, lse, st);
   return check_launch("attention_fwd");
 }

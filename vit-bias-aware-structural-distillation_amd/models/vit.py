@@ -151,6 +151,25 @@ class _PackedFlashAttention(torch.autograd.Function):
         return dqkv.view(b, t, 3 * heads * head_dim), None, None
 
 
+class _FusedAttention(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(hd)) V of a TRAINED block on the hand-written kernels: forward = the fused attention
+    kernel the frozen teacher uses, with the log-sum-exp written out; backward = ``basd_attention_bwd_bf16`` (P
+    recomputed from Q, K and the LSE, gradient delivered already packed as [B, T, 3 * H * hd])."""
+
+    @staticmethod
+    def forward(ctx, qkv_flat, heads, head_dim, scale):
+        out, _, lse = get_ops().attention_fwd(qkv_flat, heads, head_dim, scale, want_lse=True)
+        ctx.save_for_backward(qkv_flat, out, lse)
+        ctx.dims = (heads, head_dim, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv_flat, out, lse = ctx.saved_tensors
+        heads, head_dim, scale = ctx.dims
+        return get_ops().attention_bwd(qkv_flat, out, g, lse, heads, head_dim, scale), None, None, None
+
+
 _FUSED_TEACHER_ATTENTION = os.environ.get("BASD_FUSED_ATTN", "1") == "1"     # 0: library SDPA + separate tap (A/B runs)
 _packed_attention_ok = True      # cleared on the first failure of the direct library call (other torch builds)
 
@@ -181,6 +200,11 @@ class Attention(nn.Module):
                     q_, k_, _ = qkv_flat.reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
                     self.tap["out"] = self._importance(q_, k_, self.tap["has_cls"])
             return self.proj(out_flat)
+        if (torch.is_grad_enabled() and qkv_flat.requires_grad and qkv_flat.dtype == torch.bfloat16 and self.tap is None
+                and get_ops().handles(qkv_flat) and get_ops().attention_fwd_supported(t, self.head_dim)
+                and get_ops().attention_bwd_supported(t, self.head_dim)):
+            # trained block (the student): hand-written forward (+ LSE) and backward kernels
+            return self.proj(_FusedAttention.apply(qkv_flat.contiguous(), self.num_heads, self.head_dim, self.scale))
         qkv = qkv_flat.reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
         if self.tap is not None:
