@@ -81,3 +81,87 @@ def test_reducer_is_a_noop_without_process_group():
     g = flat.grad.clone()
     red.finish()
     torch.testing.assert_close(flat.grad, g, atol=0, rtol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The REAL trainer on two ranks (BASELINE c1 shapes, kernels emulated on CPU): per-rank loss parity on the rank's shard,
+# gradient mean through both reduction paths (bucket hooks + finish(), and the single reduce_all() used after a hipGraph
+# replay), temperatures averaged with the student parameters.
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "vit-bias-aware-structural-distillation_amd", "configs", "config.yaml")
+
+
+def _c1_trainer():
+    from basd_amd.config import load_config
+    from basd_amd.losses import _ops
+    from basd_amd.train import build
+    from tests import _emul
+    _ops.set_ops(_emul)
+    torch.manual_seed(0)
+    cfg = load_config(CFG, "basd_cifar100", ["data.batch_size=8", "model.drop_path_rate=0.0", "basd.bucket_mb=4"])
+    trainer, _ = build(cfg, device="cpu")
+    trainer.use_mixup = False
+    trainer.optimizer.train()
+    trainer.model.train()
+    with torch.no_grad():      # distinct temperatures so that their gradients are not symmetric
+        trainer.basd_loss.layer_selector.log_temperatures.add_(torch.linspace(-0.3, 0.3, 4))
+    return trainer
+
+
+def _shard(rank):
+    from basd_amd.train import SyntheticLoader
+    return next(iter(SyntheticLoader(8, 32, 100, 1, "cpu", seed=50 + rank)))
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    trainer = _c1_trainer()
+    assert trainer.reducer.enabled and trainer.reducer.world == 2 and len(trainer.reducer.buckets) >= 5
+    batch = _shard(rank)
+    out = {}
+    # path 1: bucket hooks fire during backward, finish() waits and averages
+    loss, _ = trainer._forward_backward(batch["clean"], batch["augmented"], batch["label"])
+    trainer.reducer.finish()
+    out["loss"], out["grad_hooks"] = loss.clone(), trainer.flat.grad.clone()
+    trainer.flat.zero_grad()
+    # path 2: hooks paused (what a captured graph replay does), one all-reduce over the flat buffer
+    trainer.reducer.paused = True
+    trainer._forward_backward(batch["clean"], batch["augmented"], batch["label"])
+    trainer.reducer.reduce_all()
+    out["grad_all"] = trainer.flat.grad.clone()
+    n_t = trainer.basd_loss.layer_selector.log_temperatures.numel()
+    out["temp_grad"] = trainer.basd_loss.layer_selector.log_temperatures.grad.clone()
+    assert n_t == 4
+    torch.save(out, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_trainer_shards_losses_and_gradient_mean(tmp_path):
+    port = _free_port()
+    mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / f"t{r}.pt") for r in range(2)]
+    # single-process reference on each shard with the same (seeded) weights
+    from basd_amd.losses import _ops
+    try:
+        trainer = _c1_trainer()
+        want_loss, want_grad = [], torch.zeros_like(trainer.flat.grad)
+        for r in range(2):
+            trainer.flat.zero_grad()
+            b = _shard(r)
+            loss, _ = trainer._forward_backward(b["clean"], b["augmented"], b["label"])
+            want_loss.append(loss.clone())
+            want_grad += trainer.flat.grad / 2
+    finally:
+        _ops.set_ops(None)
+    for r in range(2):
+        torch.testing.assert_close(got[r]["loss"], want_loss[r], rtol=1e-6, atol=0)       # (i) per-rank loss on its shard
+        torch.testing.assert_close(got[r]["grad_hooks"], want_grad, rtol=1e-5, atol=1e-7)  # (ii) finish()
+        torch.testing.assert_close(got[r]["grad_all"], want_grad, rtol=1e-5, atol=1e-7)    # (ii) reduce_all()
+    torch.testing.assert_close(got[0]["grad_hooks"], got[1]["grad_hooks"], rtol=0, atol=0)
+    # (iii) the four temperatures sit in the same flat buffer: averaged, identical on both ranks, and not zero
+    torch.testing.assert_close(got[0]["temp_grad"], got[1]["temp_grad"], rtol=0, atol=0)
+    torch.testing.assert_close(got[0]["temp_grad"], want_grad[-64:][:4], rtol=1e-5, atol=1e-9)
+    assert float(got[0]["temp_grad"].abs().max()) > 0

@@ -57,6 +57,10 @@ class GradientReducer:
             for idx in mem:
                 self._bucket_of[idx] = b
         self._pending = [len(m) for _, _, m in self.buckets]
+        # a parameter reports ONCE per backward: layers that accumulate straight into the flat buffer call
+        # _basd_ready themselves AND autograd may still run the post-accumulate hook for them; counting both let a
+        # bucket go out when half of its gradients were still missing (found by the two-rank trainer test)
+        self._seen = [False] * len(flat.params)
         for idx, p in enumerate(flat.params):
             hook = self._make_hook(idx)
             self._hooks.append(p.register_post_accumulate_grad_hook(hook))
@@ -65,8 +69,9 @@ class GradientReducer:
 
     def _make_hook(self, idx):
         def hook(_param):
-            if self.paused:
+            if self.paused or self._seen[idx]:
                 return
+            self._seen[idx] = True
             b = self._bucket_of[idx]
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -91,6 +96,7 @@ class GradientReducer:
         self._handles.clear()
         self.flat.grad.div_(self.world)
         self._pending = [len(m) for _, _, m in self.buckets]
+        self._seen = [False] * len(self._seen)
 
     def reduce_all(self):
         """One all-reduce over the whole flat gradient buffer (used after a hipGraph replay, where the

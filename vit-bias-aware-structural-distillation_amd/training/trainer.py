@@ -72,6 +72,8 @@ class Trainer:
         lin_params = [q for m in student_model.modules() if isinstance(m, (BasdLinear, MixedLayerNorm))
                       for q in m.parameters()]
         self.flat.enable_bf16_shadow(lin_params)
+        if config.basd.get("bucket_mb") is not None:          # optional key: all-reduce bucket size in MiB
+            bucket_bytes = int(float(config.basd.bucket_mb) * (1 << 20))
         self.reducer = GradientReducer(self.flat, bucket_bytes=bucket_bytes)
         self.reducer.broadcast_parameters()
         self.optimizer.z.copy_(self.flat.data)
