@@ -1,0 +1,85 @@
+"""Evaluation surface (reference src/evaluation/metrics.py): top-1 / top-5 accuracy, class-subset evaluation,
+efficiency record, metrics.json structure."""
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from basd_amd.evaluation import evaluate_model, measure_efficiency, run_eval_suite, save_metrics
+
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "vit-bias-aware-structural-distillation_amd", "configs", "config.yaml")
+
+
+class _Table(nn.Module):
+    """logits looked up from the first pixel: lets the test prescribe every prediction"""
+
+    def __init__(self, logits):
+        super().__init__()
+        self.table = nn.Parameter(logits, requires_grad=False)
+
+    def forward(self, x):
+        return self.table[x[:, 0, 0, 0].long()]
+
+
+def _loader(n, bs=4):
+    for i in range(0, n, bs):
+        idx = torch.arange(i, min(i + bs, n))
+        yield {"pixel_values": idx.float().view(-1, 1, 1, 1).expand(-1, 3, 2, 2).clone(), "label": labels[idx]}
+
+
+torch.manual_seed(0)
+logits = torch.randn(10, 8)
+labels = torch.randint(0, 8, (10,))
+
+
+def test_top1_top5_and_loss_match_a_manual_count():
+    m = evaluate_model(_Table(logits), _loader(10), nn.CrossEntropyLoss(), num_classes=8)
+    order = logits.argsort(dim=1, descending=True)
+    assert m["val_acc"] == 100.0 * float((order[:, 0] == labels).float().mean())
+    assert m["val_acc_top5"] == 100.0 * float((order[:, :5] == labels[:, None]).any(1).float().mean())
+    assert abs(m["loss"] - float(nn.functional.cross_entropy(logits, labels))) < 1e-6
+
+
+def test_class_subset_evaluation():
+    global labels
+    keep = [1, 3, 4, 6]
+    full = labels
+    try:
+        labels = torch.randint(0, 4, (10,))                 # labels index the SUBSET, as in the reference
+        m = evaluate_model(_Table(logits), _loader(10), nn.CrossEntropyLoss(), num_classes=4, valid_indices=keep)
+        sub = logits[:, keep]
+        assert m["val_acc"] == 100.0 * float((sub.argmax(1) == labels).float().mean())
+        assert m["val_acc_top5"] == 100.0                   # top-5 of 4 classes
+    finally:
+        labels = full
+
+
+def test_eval_suite_structure_and_metrics_json(tmp_path):
+    from basd_amd.config import load_config
+    from basd_amd.models.vit import create_vit
+    cfg = load_config(CFG, "basd_cifar100", ["data.eval_datasets=[extra]"])
+    model = create_vit("deit_tiny_patch16_224", num_classes=100, img_size=32, patch_size=4)
+
+    def ds(n, classes=100):
+        g = torch.Generator().manual_seed(n)
+        return [{"pixel_values": torch.randn(4, 3, 32, 32, generator=g),
+                 "label": torch.randint(0, classes, (4,), generator=g)} for _ in range(n)]
+    res = run_eval_suite(model, cfg, config_path="configs/config.yaml",
+                         loaders={cfg.data.dataset: ds(2), "extra": (ds(1, 50), list(range(0, 100, 2)))},
+                         efficiency_kwargs=dict(batch_size=2, num_warmup=1, num_batches=2))
+    assert set(res) == {"run", "primary", "robustness", "efficiency"}
+    assert set(res["primary"]) == {"dataset", "val_acc", "val_acc_top5", "loss"} and set(res["robustness"]) == {"extra"}
+    eff = res["efficiency"]
+    assert eff["param_count"] == sum(p.numel() for p in model.parameters()) and eff["throughput_img_per_sec"] > 0
+    # DeiT-T on 64 + 1 tokens: 12 blocks x (24 T D^2 + 4 T^2 D) + patch embed + head, within the counter's conventions
+    assert 0.3 < eff["gflops"] < 1.2
+    path = save_metrics(res, tmp_path)
+    assert json.loads(path.read_text())["run"]["name"] == cfg.run.name
+
+
+def test_measure_efficiency_counts_parameters():
+    m = measure_efficiency(nn.Sequential(nn.Flatten(), nn.Linear(3 * 8 * 8, 10)), image_size=8, batch_size=2, num_warmup=1,
+                           num_batches=2)
+    assert m["param_count"] == 3 * 64 * 10 + 10 and abs(m["gflops"] - 2 * 192 * 10 / 1e9) < 1e-12

@@ -97,6 +97,27 @@ def test_teacher_tap_equals_full_attention_map():
         torch.testing.assert_close(imp[i], maps[i][:, :, 0, 1:].mean(1), atol=1e-6, rtol=1e-5)
 
 
+def test_layerscale_teacher_is_folded_exactly():
+    """DINOv2-style teacher (the reference's default): LayerScale folded into proj / fc2 at load time == the unfolded
+    model, and the loaded teacher has no LayerScale left (so its blocks take the fused path)"""
+    from basd_amd.models.teacher import fold_layerscale
+    from basd_amd.models.vit import LayerScale, create_vit
+    torch.manual_seed(0)
+    ref = create_vit("dinov2_vits14", num_classes=0, img_size=28).eval()
+    for m in ref.modules():
+        if isinstance(m, LayerScale):
+            torch.nn.init.uniform_(m.gamma, 0.1, 2.0)
+    for p in ref.parameters():
+        p.requires_grad = False
+    x = torch.randn(2, 3, 28, 28)
+    want = ref(x)
+    assert fold_layerscale(ref) == 24 and not any(isinstance(m, LayerScale) for m in ref.modules())
+    torch.testing.assert_close(ref(x), want, rtol=1e-5, atol=1e-5)
+    from basd_amd.models import load_teacher
+    t = load_teacher("dinov2_vits14", 28, device="cpu", dtype=torch.float32)
+    assert not any(isinstance(m, LayerScale) for m in t.model.modules()) and t.has_cls_token
+
+
 def test_probe_finds_vit_blocks_and_resnet_stages():
     """probe_model: the reference's key set; ViT `blocks`, and the `layer1..4` family of ResNets its probe cannot see"""
     from basd_amd.models import probe_model

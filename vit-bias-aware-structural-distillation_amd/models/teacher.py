@@ -105,6 +105,34 @@ def probe_model(model: nn.Module, img_size: int) -> dict:
     }
 
 
+@torch.no_grad()
+def fold_layerscale(model: nn.Module) -> int:
+    """Frozen LayerScale teachers (DINOv2, the reference's default ``dinov2_vitb14``, configs/config.yaml:38):
+    ``gamma * (W x + b)`` is the linear layer ``(diag(gamma) W) x + gamma b``, so every ``ls1`` / ``ls2`` is folded
+    into the projection in front of it (exact in fp32, done before the bf16 cast) and replaced by ``nn.Identity``:
+    the blocks then take the fused inference path (residual add + LayerNorm kernel, GEMM epilogues) like a plain ViT.
+    Returns the number of folded scales."""
+    folded = 0
+    for block in model.modules():
+        for ls_name, lin_path in (("ls1", "attn.proj"), ("ls2", "mlp.fc2")):
+            ls = getattr(block, ls_name, None)
+            if ls is None or isinstance(ls, nn.Identity) or not hasattr(ls, "gamma"):
+                continue
+            try:
+                lin = block.get_submodule(lin_path)
+            except AttributeError:
+                continue
+            if not isinstance(lin, nn.Linear) or lin.weight.requires_grad:
+                continue
+            gamma = ls.gamma.detach().to(lin.weight.dtype)
+            lin.weight.mul_(gamma.unsqueeze(1))
+            if lin.bias is not None:
+                lin.bias.mul_(gamma)
+            setattr(block, ls_name, nn.Identity())
+            folded += 1
+    return folded
+
+
 def load_teacher(model_name: str, img_size: int, *, weights: str | None = None, device="cuda",
                  seed: int = 42, patch_size: int | None = None, dtype=torch.bfloat16) -> TeacherModel:
     """Build (not download: reference teacher.py:113-148 fetches from the network) the named teacher -- a ViT preset of
@@ -127,6 +155,7 @@ def load_teacher(model_name: str, img_size: int, *, weights: str | None = None, 
     model = model.to(device).eval()
     for p in model.parameters():
         p.requires_grad = False
+    fold_layerscale(model)
     info = probe_model(model, img_size)
     model = model.to(dtype)
     if info["feature_format"] != "token" and torch.device(device).type == "cuda":

@@ -82,6 +82,22 @@ class SyntheticLoader:
         return self.steps
 
 
+class SyntheticEvalLoader:
+    """Evaluation batches with the reference's eval contract {"pixel_values", "label"} (src/data/datasets.py:97-123)."""
+
+    def __init__(self, batch_size, img_size, num_classes, steps, device, seed=4321):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.batches = [{"pixel_values": torch.randn(batch_size, 3, img_size, img_size, generator=g).to(device),
+                         "label": torch.randint(0, num_classes, (batch_size,), generator=g).to(device)}
+                        for _ in range(steps)]
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
 def build(config, device="cuda"):
     torch.manual_seed(config.run.seed)
     img_size = config.model.vit.img_size
@@ -120,7 +136,19 @@ def main(argv=None):
     if config.checkpoint.get("resume_from"):            # reference src/train.py:147-149
         start_epoch = trainer.load_checkpoint(config.checkpoint.resume_from)
         print(f"resumed_from={config.checkpoint.resume_from} start_epoch={start_epoch}")
-    trainer.train(loader, None, start_epoch=start_epoch)
+    from .evaluation import evaluate_model, run_eval_suite, save_metrics
+    val = SyntheticEvalLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes, 2,
+                              trainer.device)
+    crit = nn.CrossEntropyLoss()
+    trainer.train(loader, val, start_epoch=start_epoch,
+                  evaluate_fn=lambda m, l: evaluate_model(m, l, crit, num_classes=config.model.num_classes))
+    # reference src/train.py:153-160: evaluation weights (optimizer.eval()), eval suite, metrics.json
+    trainer.optimizer.eval()
+    results = run_eval_suite(trainer.model, config, config_path=args.config, loaders={config.data.dataset: val},
+                             efficiency_kwargs=dict(num_warmup=5, num_batches=20))
+    out_dir = os.path.join(config.run.output_dir, config.run.name)
+    os.makedirs(out_dir, exist_ok=True)
+    print(f"metrics_json={save_metrics(results, out_dir)}")
 
 
 if __name__ == "__main__":
