@@ -201,13 +201,18 @@ int basd_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, floa
  * (fp32 atomics; pass NULL for a frozen layer).  D % 8 == 0, D <= 2048. */
 int basd_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, int64_t rows, int D,
                             float eps, void* y, float* mean, float* rstd, void* stream);
-/* Pre-norm residual step of a frozen block: sum_out = bf16(x + residual), y = LayerNorm(sum_out).
- * mean / rstd may be NULL. */
+/* Pre-norm residual step of a block: sum_out = bf16(residual + scale * x), y = LayerNorm(sum_out).
+ * row_scale (nullable, fp32 [rows / rows_per_scale]): per-SAMPLE scale of the branch x = the stochastic-depth keep
+ * mask divided by the keep probability (timm DropPath); NULL = 1.  mean / rstd may be NULL (frozen block). */
 int basd_add_layernorm_fwd_bf16(const void* x, const void* residual, const float* gamma, const float* beta,
                                 int64_t rows, int D, float eps, void* sum_out, void* y, float* mean,
-                                float* rstd, void* stream);
+                                float* rstd, const float* row_scale, int rows_per_scale, void* stream);
+/* dx = LayerNorm backward (+ dres when given: the gradient that arrives through the residual connection of a pre-norm
+ * block, so dx is the whole gradient of the block's residual stream); dbranch (nullable) = row_scale * dx, the
+ * gradient of the branch input of basd_add_layernorm_fwd_bf16.  dgamma / dbeta are accumulated (nullable). */
 int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean,
                             const float* rstd, int64_t rows, int D, void* dx, float* dgamma, float* dbeta,
+                            const void* dres, void* dbranch, const float* row_scale, int rows_per_scale,
                             void* stream);
 
 /* Row epilogue of the Procrustes backward (reference src/losses/relational.py:22-45 differentiated):

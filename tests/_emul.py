@@ -270,10 +270,13 @@ def cls_importance(qkv, heads, head_dim, scale):
     return logits.softmax(dim=-1)[:, :, 1:].mean(dim=1)
 
 
-def add_layernorm_fwd(x, residual, gamma, beta, eps):
-    s = (x.float() + residual.float()).to(torch.bfloat16)
-    y, _, _ = layernorm_fwd(s, gamma, beta, eps)
-    return s, y
+def add_layernorm_fwd(x, residual, gamma, beta, eps, row_scale=None, want_stats=False):
+    xf = x.float()
+    if row_scale is not None:
+        xf = xf * row_scale.float().view(-1, *([1] * (x.dim() - 1)))
+    s = (xf + residual.float()).to(torch.bfloat16)
+    y, mean, rstd = layernorm_fwd(s, gamma, beta, eps)
+    return (s, y, mean, rstd) if want_stats else (s, y)
 
 
 def attention_fwd_supported(t, hd):
@@ -321,7 +324,7 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean.reshape(-1), rstd.reshape(-1)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, row_scale=None, want_branch=False):
     d = x.shape[-1]
     xf, dyf = x.float().reshape(-1, d), dy.float().reshape(-1, d)
     xh = (xf - mean.unsqueeze(-1)) * rstd.unsqueeze(-1)
@@ -330,4 +333,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
     if dgamma is not None:
         dgamma.add_((dyf * xh).sum(0))
         dbeta.add_(dyf.sum(0))
-    return dx.to(torch.bfloat16).reshape(x.shape)
+    if dres is not None:
+        dx = dx + dres.float().reshape(-1, d)
+    out = dx.to(torch.bfloat16).reshape(x.shape)
+    if not want_branch:
+        return out
+    sc = 1.0 if row_scale is None else row_scale.float().view(-1, *([1] * (x.dim() - 1)))
+    return out, (dx.reshape(x.shape) * sc).to(torch.bfloat16)

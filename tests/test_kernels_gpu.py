@@ -492,6 +492,35 @@ def test_add_layernorm_equals_add_then_layernorm(nat, rows, D):
     assert torch.equal(y, y_ref)
 
 
+@pytest.mark.parametrize("B,T,D", [(6, 197, 192), (3, 65, 384), (2, 50, 768)])
+def test_add_layernorm_with_drop_path_scale_and_fused_backward(nat, B, T, D):
+    """trained-block variant: s = residual + scale[sample] * branch with saved statistics; backward adds the residual
+    gradient and emits the scaled branch gradient -- against fp32 torch on the same bf16 inputs"""
+    g = torch.Generator().manual_seed(B * 100 + D)
+    x = (torch.randn(B, T, D, generator=g) * 2.0).bfloat16().cuda()
+    r = torch.randn(B, T, D, generator=g).bfloat16().cuda()
+    scale = (torch.bernoulli(torch.full((B,), 0.7), generator=g) / 0.7).cuda()
+    gamma = (torch.randn(D, generator=g) * 0.5 + 1.0).cuda()
+    beta = (torch.randn(D, generator=g) * 0.1).cuda()
+    s, y, mean, rstd = nat.add_layernorm_fwd(x, r, gamma, beta, 1e-6, row_scale=scale, want_stats=True)
+    s_ref = (r.float() + scale.view(-1, 1, 1) * x.float()).bfloat16()
+    assert torch.equal(s, s_ref)
+    y_ref, m_ref, r_ref = nat.layernorm_fwd(s_ref, gamma, beta, 1e-6)
+    assert torch.equal(y, y_ref) and torch.allclose(mean, m_ref) and torch.allclose(rstd, r_ref)
+    dy = torch.randn(B, T, D, generator=g).bfloat16().cuda()
+    dres = torch.randn(B, T, D, generator=g).bfloat16().cuda()
+    dgam, dbet = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx, dbr = nat.layernorm_bwd(dy, s, gamma, mean, rstd, dgam, dbet, dres=dres, row_scale=scale, want_branch=True)
+    sf = s.float().requires_grad_(True)
+    gm = gamma.clone().requires_grad_(True)
+    bt = beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(sf, (D,), gm, bt, 1e-6).backward(dy.float())
+    want = sf.grad + dres.float()
+    assert float((dx.float() - want).abs().max()) < 2e-2 * float(want.abs().max())
+    assert float((dbr.float() - scale.view(-1, 1, 1) * want).abs().max()) < 2e-2 * float(want.abs().max()) * float(scale.max())
+    assert torch.allclose(dgam, gm.grad, rtol=2e-3, atol=2e-2) and torch.allclose(dbet, bt.grad, rtol=2e-3, atol=2e-2)
+
+
 @pytest.mark.parametrize("B,T,H,hd", [(5, 197, 12, 64), (3, 50, 3, 64), (2, 256, 6, 32), (4, 2, 1, 64)])
 def test_cls_importance_matches_the_attention_map(nat, B, T, H, hd):
     """head-averaged CLS row of softmax(QK^T/sqrt(hd)) without the CLS column (teacher.py:33-37,

@@ -97,6 +97,29 @@ def test_teacher_tap_equals_full_attention_map():
         torch.testing.assert_close(imp[i], maps[i][:, :, 0, 1:].mean(1), atol=1e-6, rtol=1e-5)
 
 
+def test_fused_residual_layernorm_blocks_equal_the_plain_blocks():
+    """trained blocks: residual add (+ stochastic depth) fused with the following LayerNorm, and the residual gradient
+    added inside the LayerNorm backward, against the plain addcmul / LayerNorm sequence -- same masks, same weights"""
+    from basd_amd.models.vit import create_vit
+    torch.manual_seed(0)
+    model = create_vit("deit_tiny_patch16_224", num_classes=10, img_size=32, patch_size=4, drop_path_rate=0.3).train()
+    x = torch.randn(6, 3, 32, 32)
+    out = {}
+    for fused in (True, False):
+        for blk in model.blocks:
+            blk.fuse_training = fused
+        model.zero_grad()
+        torch.manual_seed(7)                      # same stochastic-depth masks
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y = model(x)
+        y.float().square().mean().backward()
+        out[fused] = (y.detach().float(), torch.cat([p.grad.flatten() for p in model.parameters()]))
+    assert float((out[True][0] - out[False][0]).abs().max()) < 3e-2 * float(out[False][0].abs().max())
+    g1, g0 = out[True][1].double(), out[False][1].double()
+    assert float(torch.dot(g1, g0) / (g1.norm() * g0.norm())) > 0.999
+    assert abs(float(g1.norm() / g0.norm()) - 1.0) < 2e-2
+
+
 def test_layerscale_teacher_is_folded_exactly():
     """DINOv2-style teacher (the reference's default): LayerScale folded into proj / fc2 at load time == the unfolded
     model, and the loaded teacher has no LayerScale left (so its blocks take the fused path)"""

@@ -104,6 +104,29 @@ def test_non_finite_input_raises_a_linalg_error_one_step_late():
         trainer.train_step(batch)                # ... and looked at when the next one starts
 
 
+def test_fused_residual_layernorm_blocks_match_plain_blocks_on_gpu():
+    """the fused add + LayerNorm (+ stochastic depth) step of trained blocks and its backward on the HIP kernels against
+    the unfused sequence (torch addcmul, separate LayerNorm forward / backward kernels), same masks and weights"""
+    from basd_amd.models.vit import create_vit
+    torch.manual_seed(0)
+    model = create_vit("deit_tiny_patch16_224", num_classes=100, img_size=224, drop_path_rate=0.2).cuda().train()
+    x = torch.randn(16, 3, 224, 224, device="cuda")
+    out = {}
+    for fused in (True, False):
+        for blk in model.blocks:
+            blk.fuse_training = fused
+        model.zero_grad()
+        torch.manual_seed(3)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        y.float().square().mean().backward()
+        out[fused] = (y.detach().float(), torch.cat([p.grad.flatten() for p in model.parameters()]).double())
+    assert float((out[True][0] - out[False][0]).abs().max()) < 3e-2 * float(out[False][0].abs().max())
+    g1, g0 = out[True][1], out[False][1]
+    assert float(torch.dot(g1, g0) / (g1.norm() * g0.norm())) > 0.999
+    assert abs(float(g1.norm() / g0.norm()) - 1.0) < 2e-2
+
+
 def test_eager_step_is_deterministic_up_to_atomics():
     a, batch = _make(16)
     b, _ = _make(16)

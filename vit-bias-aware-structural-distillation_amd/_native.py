@@ -44,8 +44,8 @@ _SIGNATURES = {
     "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
     "basd_gemm_bf16": (_P, _P, _P, _P, _I64, _I, _I, _I, _P),
     "basd_layernorm_fwd_bf16": (_P, _P, _P, _I64, _I, _F, _P, _P, _P, _P),
-    "basd_add_layernorm_fwd_bf16": (_P, _P, _P, _P, _I64, _I, _F, _P, _P, _P, _P, _P),
-    "basd_layernorm_bwd_bf16": (_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P),
+    "basd_add_layernorm_fwd_bf16": (_P, _P, _P, _P, _I64, _I, _F, _P, _P, _P, _P, _P, _I, _P),
+    "basd_layernorm_bwd_bf16": (_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _I, _P),
     "basd_procrustes_bwd_rows": (_P, _P, _P, _P, _I64, _I, _I, _P, _I, _P, _P),
     "basd_cls_importance_bf16": (_P, _I, _I, _I, _I, _F, _P, _P),
     "basd_attention_fwd_bf16": (_P, _I, _I, _I, _I, _F, _P, _P, _P, _P),
@@ -580,8 +580,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     return y, mean, rstd
 
 
-def add_layernorm_fwd(x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
-    """(x + residual) rounded to bf16 and its LayerNorm: -> (sum bf16, y bf16).  Inference only (no statistics kept)."""
+def add_layernorm_fwd(x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                      row_scale: torch.Tensor | None = None, want_stats: bool = False):
+    """s = bf16(residual + row_scale[sample] * x) and y = LayerNorm(s): -> (s, y) or, with ``want_stats`` (a trained
+    block: backward needs them), (s, y, mean, rstd).  ``row_scale`` fp32 [B] for x [B, T, D] (stochastic depth)."""
     _need_cuda(x, residual, gamma, beta)
     assert x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16 and x.shape == residual.shape
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
@@ -590,21 +592,37 @@ def add_layernorm_fwd(x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tens
     rows = x.numel() // d
     s = torch.empty_like(x)
     y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rps = 1
+    if row_scale is not None:
+        row_scale = row_scale.contiguous().float()
+        assert rows % row_scale.numel() == 0
+        rps = rows // row_scale.numel()
     _check(lib().basd_add_layernorm_fwd_bf16(_ptr(x), _ptr(residual), _ptr(gamma.contiguous()), _ptr(beta.contiguous()),
-                                             ctypes.c_int64(rows), d, ctypes.c_float(eps), _ptr(s), _ptr(y), None, None,
-                                             _stream()), "basd_add_layernorm_fwd_bf16")
-    return s, y
+                                             ctypes.c_int64(rows), d, ctypes.c_float(eps), _ptr(s), _ptr(y), _ptr(mean),
+                                             _ptr(rstd), _ptr(row_scale), rps, _stream()), "basd_add_layernorm_fwd_bf16")
+    return (s, y, mean, rstd) if want_stats else (s, y)
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
-                  dgamma: torch.Tensor | None, dbeta: torch.Tensor | None) -> torch.Tensor:
-    """-> dx bf16; dgamma / dbeta (fp32, may be None together) are accumulated into."""
+                  dgamma: torch.Tensor | None, dbeta: torch.Tensor | None, dres: torch.Tensor | None = None,
+                  row_scale: torch.Tensor | None = None, want_branch: bool = False):
+    """-> dx bf16 (= LayerNorm backward + ``dres``); with ``want_branch`` -> (dx, row_scale[sample] * dx).
+    dgamma / dbeta (fp32, may be None together) are accumulated into."""
     _need_cuda(dy, x, gamma)
     dy = dy.contiguous()
     d = x.shape[-1]
     rows = x.numel() // d
     dx = torch.empty_like(x)
+    dbranch = torch.empty_like(x) if want_branch else None
+    rps = 1
+    if dres is not None:
+        dres = dres.to(torch.bfloat16).contiguous()
+    if row_scale is not None:
+        row_scale = row_scale.contiguous().float()
+        rps = rows // row_scale.numel()
     _check(lib().basd_layernorm_bwd_bf16(_ptr(dy), _ptr(x), _ptr(gamma.contiguous()), _ptr(mean), _ptr(rstd),
-                                         ctypes.c_int64(rows), d, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()),
-           "basd_layernorm_bwd_bf16")
-    return dx
+                                         ctypes.c_int64(rows), d, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(dres),
+                                         _ptr(dbranch), _ptr(row_scale), rps, _stream()), "basd_layernorm_bwd_bf16")
+    return (dx, dbranch) if want_branch else dx

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int64_t rows, int D, float eps, unsigned short* __restrict__ sum_out,
                                                      unsigned short* __restrict__ y, float* __restrict__ mean,
-                                                     float* __restrict__ rstd) {
+                                                     float* __restrict__ rstd, const float* __restrict__ row_scale,
+                                                     int rows_per_scale) {
   constexpr int RPW = 64 / G;                       // rows per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lg = lane & (G - 1), sub = lane / G;
@@ -89,8 +90,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
         if (FUSE_ADD) {
           float fr[8];
           unpack8(*reinterpret_cast<const uint4*>(res + r * D + ch * 8), fr);
+          // stochastic depth of a trained block: the branch x is scaled per SAMPLE (keep mask / keep probability)
+          const float sc = row_scale ? row_scale[r / rows_per_scale] : 1.f;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) f[c][i] = round_bf16(f[c][i] + fr[i]);
+          for (int i = 0; i < 8; ++i) f[c][i] = round_bf16(fmaf(sc, f[c][i], fr[i]));
           uint4 o;
           o.x = pack2(f[c][0], f[c][1]); o.y = pack2(f[c][2], f[c][3]); o.z = pack2(f[c][4], f[c][5]); o.w = pack2(f[c][6], f[c][7]);
           *reinterpret_cast<uint4*>(sum_out + r * D + ch * 8) = o;
@@ -136,7 +139,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int64_t rows, int D,
                                                      unsigned short* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
+                                                     float* __restrict__ dbeta, const unsigned short* __restrict__ dres,
+                                                     unsigned short* __restrict__ dbranch,
+                                                     const float* __restrict__ row_scale, int rows_per_scale) {
   extern __shared__ float acc[];                    // [4 waves][2][D] column partials
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -184,9 +189,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = rs * (gg[c][i] - m1 - xh[c][i] * m2);
+        if (dres != nullptr) {                      // gradient arriving through the residual path of a pre-norm block
+          float fr[8];
+          unpack8(*reinterpret_cast<const uint4*>(dres + r * D + ch * 8), fr);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += fr[i];
+        }
         uint4 out;
         out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
         *reinterpret_cast<uint4*>(dx + r * D + ch * 8) = out;
+        if (dbranch != nullptr) {                   // gradient of the (stochastic-depth scaled) branch input
+          const float sc = row_scale ? row_scale[r / rows_per_scale] : 1.f;
+          out.x = pack2(sc * o[0], sc * o[1]); out.y = pack2(sc * o[2], sc * o[3]);
+          out.z = pack2(sc * o[4], sc * o[5]); out.w = pack2(sc * o[6], sc * o[7]);
+          *reinterpret_cast<uint4*>(dbranch + r * D + ch * 8) = out;
+        }
       }
     }
   }
@@ -226,7 +243,8 @@ static int ln_grid(int64_t rows, int rows_per_wg, int cap = 2048) {
 
 template <bool FUSE>
 static int launch_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, int64_t rows, int D,
-                         float eps, void* sum_out, void* y, float* mean, float* rstd, hipStream_t st) {
+                         float eps, void* sum_out, void* y, float* mean, float* rstd, const float* row_scale,
+                         int rows_per_scale, hipStream_t st) {
   const int nchunk = D / 8;
   const unsigned short* xp = (const unsigned short*)x;
   const unsigned short* rp = (const unsigned short*)res;
@@ -234,7 +252,7 @@ static int launch_ln_fwd(const void* x, const void* res, const float* gamma, con
   unsigned short* yp = (unsigned short*)y;
 #define BASD_LN_FWD(G, NCH)                                                                                   \
   hipLaunchKernelGGL((ln_fwd_kernel<G, NCH, FUSE>), dim3(ln_grid(rows, 4 * (64 / G))), dim3(256), 0, st, xp, rp, \
-                     gamma, beta, rows, D, eps, sp, yp, mean, rstd)
+                     gamma, beta, rows, D, eps, sp, yp, mean, rstd, row_scale, rows_per_scale)
   if (nchunk <= 32) BASD_LN_FWD(32, 1);
   else if (nchunk <= 64) BASD_LN_FWD(64, 1);
   else if (nchunk <= 128) BASD_LN_FWD(64, 2);
@@ -251,21 +269,25 @@ extern "C" int basd_layernorm_fwd_bf16(const void* x, const float* gamma, const 
   using namespace basd;
   if (rows <= 0) return BASD_OK;
   if (D % 8 || D < 8 || D > 2048) return fail(BASD_ERR_SHAPE, "layernorm_fwd_bf16: D %% 8 != 0 or D > 2048 (%d)", D);
-  return launch_ln_fwd<false>(x, nullptr, gamma, beta, rows, D, eps, nullptr, y, mean, rstd, (hipStream_t)stream);
+  return launch_ln_fwd<false>(x, nullptr, gamma, beta, rows, D, eps, nullptr, y, mean, rstd, nullptr, 1,
+                              (hipStream_t)stream);
 }
 
 extern "C" int basd_add_layernorm_fwd_bf16(const void* x, const void* residual, const float* gamma, const float* beta,
                                            int64_t rows, int D, float eps, void* sum_out, void* y, float* mean,
-                                           float* rstd, void* stream) {
+                                           float* rstd, const float* row_scale, int rows_per_scale, void* stream) {
   using namespace basd;
   if (rows <= 0) return BASD_OK;
   if (D % 8 || D < 8 || D > 2048) return fail(BASD_ERR_SHAPE, "add_layernorm_fwd_bf16: D %% 8 != 0 or D > 2048 (%d)", D);
   if (residual == nullptr || sum_out == nullptr) return fail(BASD_ERR_SHAPE, "add_layernorm_fwd_bf16: null residual / sum_out");
-  return launch_ln_fwd<true>(x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, (hipStream_t)stream);
+  if (row_scale != nullptr && rows_per_scale < 1) return fail(BASD_ERR_SHAPE, "add_layernorm_fwd_bf16: rows_per_scale < 1");
+  return launch_ln_fwd<true>(x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, row_scale,
+                             rows_per_scale < 1 ? 1 : rows_per_scale, (hipStream_t)stream);
 }
 
 extern "C" int basd_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean,
                                        const float* rstd, int64_t rows, int D, void* dx, float* dgamma, float* dbeta,
+                                       const void* dres, void* dbranch, const float* row_scale, int rows_per_scale,
                                        void* stream) {
   using namespace basd;
   if (rows <= 0) return BASD_OK;
@@ -279,7 +301,8 @@ extern "C" int basd_layernorm_bwd_bf16(const void* dy, const void* x, const floa
 #define BASD_LN_BWD(G, NCH)                                                                                       \
   hipLaunchKernelGGL((ln_bwd_kernel<G, NCH>), dim3(ln_grid(rows, 4 * (64 / G) * 4, bwd_cap)), dim3(256), lds, st,   \
                      (const unsigned short*)dy, (const unsigned short*)x, gamma, mean, rstd, rows, D,               \
-                     (unsigned short*)dx, dgamma, dbeta)
+                     (unsigned short*)dx, dgamma, dbeta, (const unsigned short*)dres, (unsigned short*)dbranch,      \
+                     row_scale, rows_per_scale < 1 ? 1 : rows_per_scale)
   if (nchunk <= 32) BASD_LN_BWD(32, 1);
   else if (nchunk <= 64) BASD_LN_BWD(64, 1);
   else if (nchunk <= 128) BASD_LN_BWD(64, 2);

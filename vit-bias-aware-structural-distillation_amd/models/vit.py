@@ -89,6 +89,47 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, gw, gb, None
 
 
+class _AddLayerNormFn(torch.autograd.Function):
+    """One residual step of a TRAINED pre-norm block: s = residual + drop_path(branch), y = LayerNorm(s), both returned.
+    Forward: one kernel (``basd_add_layernorm_fwd_bf16`` with the per-sample stochastic-depth scale); backward: one
+    kernel that adds the gradient arriving through the residual connection to the LayerNorm backward and also emits the
+    (scaled) gradient of the branch -- instead of addcmul + LayerNorm forward, and LayerNorm backward + add (+ mul)."""
+
+    @staticmethod
+    def forward(ctx, branch, residual, scale, weight, bias, eps):
+        s, y, mean, rstd = get_ops().add_layernorm_fwd(branch, residual, weight.detach().float(), bias.detach().float(),
+                                                       eps, row_scale=scale, want_stats=True)
+        ctx.save_for_backward(s, mean, rstd)
+        ctx.scale, ctx.weight, ctx.bias = scale, weight, bias
+        return s, y
+
+    @staticmethod
+    def backward(ctx, g_s, g_y):
+        ops = get_ops()
+        s, mean, rstd = ctx.saved_tensors
+        weight, bias, scale = ctx.weight, ctx.bias, ctx.scale
+        dy = torch.zeros_like(s) if g_y is None else g_y.to(torch.bfloat16)
+        gw = gb = None
+        sink_w = sink_b = None
+        if weight.requires_grad:
+            sink_w, sink_b = getattr(weight, "_basd_grad", None), getattr(bias, "_basd_grad", None)
+            if sink_w is None or sink_b is None:
+                gw = torch.zeros_like(weight, dtype=torch.float32)
+                gb = torch.zeros_like(bias, dtype=torch.float32)
+                sink_w, sink_b = gw, gb
+        out = ops.layernorm_bwd(dy, s, weight.detach().float(), mean, rstd, sink_w, sink_b, dres=g_s, row_scale=scale,
+                                want_branch=scale is not None)
+        d_res, d_branch = out if scale is not None else (out, out)
+        if weight.requires_grad and gw is None:
+            for p in (weight, bias):
+                ready = getattr(p, "_basd_ready", None)
+                if ready is not None:
+                    ready()
+        if gw is not None:
+            gw, gb = gw.to(weight.dtype), gb.to(bias.dtype)
+        return d_branch, d_res, None, gw, gb, None
+
+
 class MixedLayerNorm(nn.LayerNorm):
     """nn.LayerNorm (same parameters) running on the fused HIP kernel for bf16 activations: bf16 in,
     bf16 out, fp32 gamma / beta / statistics.  Equal to torch's autocast behaviour (fp32 layer_norm)
@@ -97,7 +138,7 @@ class MixedLayerNorm(nn.LayerNorm):
 
     def forward(self, x):
         pre = getattr(x, "_basd_prenorm", None)
-        if pre is not None and pre[0] is self and not torch.is_grad_enabled():
+        if pre is not None and pre[0] is self:
             return pre[1]               # already produced by the fused residual-add + norm of the previous step
         if (x.dtype == torch.bfloat16 and get_ops().handles(x) and self.elementwise_affine
                 and get_ops().layernorm_supported(x.shape[-1])):
@@ -265,6 +306,7 @@ class Block(nn.Module):
         self.drop_path2 = DropPath(drop_path)
 
         self._next_norm = []            # [norm that consumes this block's output]; set by the model, not a submodule
+        self.fuse_training = True       # cleared under activation checkpointing (tensor attributes do not survive it)
 
     def _fused_inference(self, x) -> bool:
         """frozen pre-norm block on bf16 activations: the residual adds fuse into the following norms"""
@@ -273,7 +315,26 @@ class Block(nn.Module):
                 and (not self.training or (self.drop_path1.p == 0.0 and self.drop_path2.p == 0.0))
                 and self.norm2.elementwise_affine and get_ops().layernorm_supported(x.shape[-1]))
 
+    def _fused_training(self, x) -> bool:
+        """trained pre-norm block on bf16 activations: residual add (+ stochastic depth) fused with the next norm"""
+        return (torch.is_grad_enabled() and self.training and x.dtype == torch.bfloat16 and x.requires_grad
+                and get_ops().handles(x) and isinstance(self.ls1, nn.Identity) and isinstance(self.ls2, nn.Identity)
+                and self.norm2.elementwise_affine and self.fuse_training and get_ops().layernorm_supported(x.shape[-1]))
+
     def forward(self, x, dp_masks=None):
+        if self._fused_training(x):
+            m1, m2 = dp_masks if dp_masks is not None else (None, None)
+            sc1 = None if m1 is None else m1.reshape(-1).float()
+            sc2 = None if m2 is None else m2.reshape(-1).float()
+            a = self.attn(self.norm1(x))
+            x, z = _AddLayerNormFn.apply(a, x, sc1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            m = self.mlp(z)
+            nxt = self._next_norm[0] if self._next_norm else None
+            if nxt is None or not nxt.elementwise_affine:
+                return self.drop_path2.add_to(x, m, m2)
+            out, zn = _AddLayerNormFn.apply(m, x, sc2, nxt.weight, nxt.bias, nxt.eps)
+            out._basd_prenorm = (nxt, zn)
+            return out
         if self._fused_inference(x):
             a = self.attn(self.norm1(x))
             x, z = self.norm2.fused_add(x, a)
@@ -329,6 +390,8 @@ class VisionTransformer(nn.Module):
 
     def set_grad_checkpointing(self, enable: bool = True):
         self.grad_checkpointing = enable
+        for blk in self.blocks:
+            blk.fuse_training = not enable
 
     def forward_features(self, x):
         x = self.patch_embed(x)
