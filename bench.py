@@ -233,13 +233,14 @@ def main():
             # HBM bytes per launch of the biggest Jacobi launch (E*B matrices) from the committed PMC passes
             # (profiles/r01_pmc_hbm_traffic.json; bench.py cannot read PMC counters itself)
             traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                    for key, v in json.load(f)["kernels"].items():
-                        if key.startswith("basd::jacobi_blk_kernel<6>"):
-                            traffic = v["hbm_bytes_per_launch"]
-            except OSError:
-                pass
+            if big == 1024 and big_n == 192:      # the committed PMC passes were taken at this launch shape
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
+                        for key, v in json.load(f)["kernels"].items():
+                            if key.startswith("basd::jacobi_blk_kernel<6>"):
+                                traffic = v["hbm_bytes_per_launch"]
+                except OSError:
+                    pass
             kname = ("basd::jacobi_blk_kernel<6> (register-resident one-sided Jacobi, block odd-even ordering"
                      if big >= 512 and big_n <= 192 else
                      "basd::jacobi_oe_kernel (register-resident one-sided Jacobi, odd-even ordering")
@@ -256,7 +257,7 @@ def main():
                                     "(the timed steps replay one hipGraph; device events cannot be recorded inside it; "
                                     "rocprofv3 of the same command sees the graph-launched kernels: profiles/)"),
                     "mean_sweeps": sweep_sum / max(mats, 1),
-                    "traffic_source": "constant from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json), not "
+                    "traffic_source": "constant from the committed PMC passes (profiles/r02_pmc_hbm_traffic.json), not "
                                       "measured in this run" if traffic is not None else None,
                     "note": "VALU-issue-bound kernel priced against the fp32 vector = matrix peak; algorithmic (textbook) "
                             "flops = sweeps actually run (returned per matrix by the kernel) x n(n-1)/2 pairs x 14 m; the "
