@@ -130,7 +130,9 @@ int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank,
  * leading active[b] columns (and rows, if active_rows != 0); the sweeps then run over that
  * block only (rank-masked principal-angle problems, no host sync on the ranks).
  * status (optional, device int32 word, may be NULL): BASD_STATUS_NONCONVERGED / BASD_STATUS_NONFINITE are OR-ed in.
- * Requires n_cols <= 256, ld % 4 == 0, n_cols * ld * 4 + 4096 <= 160 KiB. */
+ * Requires n_cols <= 256, ld % 4 == 0 and either n_cols * ld * 4 + 4096 <= 160 KiB (matrix resident in LDS) or the
+ * register-resident forms: m_rows <= 224, or m_rows <= 384 with n_cols <= 192 (tall block pairs; with max_sweeps = 1
+ * and sort = 0 this is one visit of a block-Jacobi tournament over wider matrices). */
 int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
                     float tol, int max_sweeps, int sort,
                     float* sigma, int32_t* sweeps, const int32_t* active, int active_rows,

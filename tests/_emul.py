@@ -104,7 +104,11 @@ def pchol(a, tol=1e-13, dmax_ref=None):
     return w0, lwork, piv.int(), rank.int()
 
 
-def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True, active=None, active_rows=False):
+JACOBI_TALL_ROWS = 384
+
+
+def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True, active=None, active_rows=False,
+               flag_status=True):
     batch, n_cols, ld = w.shape
     if norm_rows is None:
         norm_rows = m_rows
@@ -122,7 +126,13 @@ def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True,
         out = torch.zeros(m_rows, n_cols, dtype=torch.float64)
         small = s < 1e-13 * max(float(s[0]), 1e-300)
         s = torch.where(small, torch.zeros_like(s), s)
-        if JACOBI_NOISE:
+        # a converged input stays put in the real kernel (no rotation fires): only perturb when there was work to do
+        nz = top.norm(dim=0) > 0
+        gcos = torch.zeros(())
+        if JACOBI_NOISE and int(nz.sum()) > 1:
+            cn = top[:, nz] / top[:, nz].norm(dim=0, keepdim=True)
+            gcos = (cn.t() @ cn - torch.eye(int(nz.sum()), dtype=torch.float64)).abs().max()
+        if JACOBI_NOISE and float(gcos) > 1e-5:
             gen = torch.Generator().manual_seed(b)
             u = u + JACOBI_NOISE * torch.randn(u.shape, generator=gen, dtype=torch.float64)
             u = u / u.norm(dim=0, keepdim=True)

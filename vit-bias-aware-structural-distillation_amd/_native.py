@@ -279,10 +279,12 @@ def pchol(a: torch.Tensor, tol: float = 1e-13, dmax_ref: torch.Tensor | None = N
 
 def jacobi_svd(w: torch.Tensor, m_rows: int, norm_rows: int | None = None, *, tol: float | None = None,
                max_sweeps: int = 40, sort: bool = True, active: torch.Tensor | None = None,
-               active_rows: bool = False):
+               active_rows: bool = False, flag_status: bool = True):
     """In-place one-sided Jacobi on w [batch, n_cols, ld] (column-major matrices).
 
     Returns (sigma [batch, n_cols], sweeps [batch]); w's columns become sigma_c * u_c.
+    ``flag_status=False``: do not report non-convergence / non-finite values into the health word (single-sweep
+    visits of a block tournament stop early on purpose).
     """
     _need_cuda(w)
     assert w.is_contiguous() and w.dtype == torch.float32
@@ -296,13 +298,16 @@ def jacobi_svd(w: torch.Tensor, m_rows: int, norm_rows: int | None = None, *, to
     _check(lib().basd_jacobi_svd(_ptr(w), batch, m_rows, n_cols, ld, norm_rows, ctypes.c_float(tol),
                                  max_sweeps, int(sort), _ptr(sigma), _ptr(sweeps),
                                  _ptr(None if active is None else active.contiguous().int()), int(active_rows),
-                                 _ptr(status_word(w.device)), _stream()),
+                                 _ptr(status_word(w.device) if flag_status else None), _stream()),
            "basd_jacobi_svd")
     return sigma, sweeps
 
 
 def jacobi_fits(n_cols: int, m_rows: int) -> bool:
     return n_cols <= 256 and n_cols * jacobi_ld(m_rows) * 4 + 520 * 4 <= JACOBI_LDS_BYTES
+
+
+JACOBI_TALL_ROWS = 384       # register-resident variant for block pairs: n_cols <= 192 columns of up to 384 rows
 
 
 def mp_rank(evals: torch.Tensor, rows: int, d: int, cap: int) -> torch.Tensor:

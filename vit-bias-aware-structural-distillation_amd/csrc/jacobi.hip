@@ -190,14 +190,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define BASD_JACOBI_QUAD 5.0e-4f
 #define BASD_JACOBI_QUAD_TAN 1.0e-2f
 
-template <int MAXCH, int NMAT>
-__global__ __launch_bounds__(NMAT == 2 ? 768 : 1024)
-__attribute__((amdgpu_waves_per_eu(NMAT == 2 ? 3 : 4, NMAT == 2 ? 3 : 4))) void jacobi_oe_kernel(
+// NBUF = 2 double-buffers the mailbox (one barrier per step); NBUF = 1 halves its LDS footprint for a second
+// barrier per step: what lets columns of up to 384 rows (MAXCH = 12: the block pairs of the D_s = 384 eigensolver,
+// 96 slots x 1.5 KiB = 147 KiB) stay register-resident.
+template <int MAXCH, int NMAT, int NBUF>
+__global__ __launch_bounds__((NMAT == 2 || MAXCH > 7) ? 768 : 1024)
+__attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 || MAXCH > 7) ? 3 : 4))) void jacobi_oe_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
     float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, const int32_t* __restrict__ active,
     int active_rows, int32_t* __restrict__ status) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int NBUF = (NMAT == 1) ? 2 : 1;
+  static_assert(NMAT == 1 || NBUF == 1, "two matrices per workgroup use one mailbox each");
   constexpr int LDM = 32 * MAXCH;                  // mailbox column stride (all MAXCH chunks, no row guards)
   const int tid = threadIdx.x;
   const int k = tid >> 3, sub = tid & 7, roff = sub * 4;
@@ -714,10 +717,18 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   const bool fits = lds_oe1 <= BASD_JACOBI_LDS_BYTES && chunks <= 7 && npairs <= 128;
 #define BASD_LAUNCH_OE(MC, NM, GRID, LDSB)                                                            \
   do {                                                                                               \
-    allow_full_lds((const void*)jacobi_oe_kernel<MC, NM>);                                            \
-    hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
+    allow_full_lds((const void*)jacobi_oe_kernel<MC, NM, (NM == 1 ? 2 : 1)>);                         \
+    hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM, (NM == 1 ? 2 : 1)>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
                        n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows, status); \
   } while (0)
+  if (chunks > 7 && chunks <= 12 && npairs <= 96) {
+    // tall columns (up to 384 rows, at most 192 of them): single mailbox, 96 slots, 3 waves per SIMD
+    const size_t lds_tall = (size_t)npairs * 32 * 12 * 4 + oe_scratch;
+    allow_full_lds((const void*)jacobi_oe_kernel<12, 1, 1>);
+    hipLaunchKernelGGL((jacobi_oe_kernel<12, 1, 1>), dim3(batch), dim3(threads), lds_tall, st, w, batch, m_rows, n_cols, ld,
+                       norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows, status);
+    return check_launch("jacobi_svd (odd-even, tall columns)");
+  }
   if (active == nullptr && batch >= 512 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
     // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
     const int nbk = (n_cols + 1) / 2, slots = (nbk + 1) / 2;
