@@ -127,6 +127,19 @@ def test_fused_residual_layernorm_blocks_match_plain_blocks_on_gpu():
     assert abs(float(g1.norm() / g0.norm()) - 1.0) < 2e-2
 
 
+def test_graph_mode_runs_a_ragged_last_batch_eagerly():
+    """a batch whose shape differs from the captured one must not be copied into the static buffers"""
+    trainer, batch = _make(32)
+    assert trainer.enable_graph(batch), trainer.graph_error
+    trainer.train_step(batch)
+    small = {k: v[:20].clone() for k, v in batch.items()}
+    loss, logits = trainer.train_step(small)
+    torch.cuda.synchronize()
+    assert logits.shape[0] == 20 and torch.isfinite(loss)
+    loss2, logits2 = trainer.train_step(batch)          # and the graph still replays afterwards
+    assert logits2.shape[0] == 32 and torch.isfinite(loss2) and trainer.optimizer.k == 3
+
+
 def test_eager_step_is_deterministic_up_to_atomics():
     a, batch = _make(16)
     b, _ = _make(16)

@@ -249,6 +249,19 @@ class Trainer:
             student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
         else:
             mixed_targets = targets
+        if self._graph is not None and (clean.shape != self._g_clean.shape or student_imgs.shape != self._g_imgs.shape):
+            # a ragged last batch (or any other shape): the captured step only fits the shapes it was captured with;
+            # copy_() would raise or, worse, broadcast a batch of one -- run this step eagerly instead
+            hooks_were_paused, self.reducer.paused = self.reducer.paused, False
+            try:
+                loss, logits = self._forward_backward(clean, student_imgs, mixed_targets)
+                self.reducer.finish()
+            finally:
+                self.reducer.paused = hooks_were_paused
+            self._post_status()
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            return loss, logits
         if self._graph is not None:
             self._g_clean.copy_(clean)
             self._g_imgs.copy_(student_imgs)
