@@ -19,6 +19,7 @@
  *                          torch.linalg.svdvals   layer_selector.py:99
  *                          matrix_norm(ord="nuc") src/losses/relational.py:48
  *   basd_mp_rank           layer_selector.py:17-20 (.median/.sum, on device, no .item())
+ *   basd_angle_weights     layer_selector.py:100-108 (acos / spectral weighting / softmax over teacher layers)
  *   basd_mix_tokens        layer_selector.py:110-112 (+ torch.stack :128-129 eliminated)
  *   basd_procrustes_prep   src/losses/relational.py:29-46, src/losses/combined.py:9-14
  *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
@@ -144,6 +145,16 @@ int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int nor
  * status (optional device int32 word): BASD_STATUS_RANK0 when a count is 0, BASD_STATUS_NONFINITE for a NaN spectrum. */
 int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int cap,
                  int32_t* ranks, int32_t* status, void* stream);
+
+/* Principal-angle distances -> mixing weights of the Grassmannian selector, fused (reference
+ * src/losses/layer_selector.py:100-108).  sigma [E, L, D] fp32: cosines of the principal angles between student
+ * extraction point i and teacher layer j (descending; zero beyond the layer's rank), sw [L, D] fp32: the teacher's
+ * singular values masked at the MP rank, log_temp [E].  Outputs (fp32): d2 [E, L] = sum_m sw theta^2 / sum_m sw with
+ * theta = acos(min(sigma, 1 - eps)); pre [E, L] = -d2 / softplus(log_temp); weights [E, L] = softmax_j(pre);
+ * coef [E, L, D] = (d d2 / d sigma) / sigma (divided by sigma^2 once more when unnormalised != 0: the caller's
+ * singular vectors are then the Jacobi's sigma_m u_m columns) -- the diagonal of the backward seed Phi.  L <= 64. */
+int basd_angle_weights(const float* sigma, const float* sw, const float* log_temp, int E, int L, int D,
+                       int unnormalised, float* d2, float* pre, float* weights, float* coef, void* stream);
 
 /* mixed[i] = sum_j w[i, j] * x_j   (all E mixes from ONE pass over the teacher layers)
  * x_layers: HOST array of L device pointers to [elems] tensors (dtype code; the pointers are

@@ -48,12 +48,16 @@ def jacobi_fits(n_cols: int, m_rows: int) -> bool:
     return n_cols <= 256 and n_cols * jacobi_ld(m_rows) * 4 + 520 * 4 <= JACOBI_LDS_BYTES
 
 
-def token_gram(x, proj, mirror=True):
+def token_gram(x, proj, mirror=True, out=None):
     x = x.reshape(-1, x.shape[-1])
     z = (x.float() @ proj.float().t()).double()
     g = z.t() @ z
     if not mirror:                                   # like the kernels: the strict upper triangle is not meaningful
         g = torch.tril(g) + torch.triu(torch.full_like(g, float("nan")), 1)
+    if out is not None:
+        out[0].copy_(g)
+        out[1].copy_(z.sum(0))
+        return out
     return g, z.sum(0)
 
 
@@ -158,6 +162,23 @@ def mp_rank(evals, rows, d, cap):
         if out[-1] == 0:
             _STATUS[0] |= 4 if math.isfinite(edge) else 2
     return torch.tensor(out, dtype=torch.int32)
+
+
+def angle_weights(sigma, sw, log_temp, unnormalised):
+    eps = float(torch.finfo(torch.float32).eps)
+    sig = sigma.float()
+    sig_c = sig.clamp(max=1.0 - eps)
+    theta = torch.acos(sig_c)
+    den = sw.sum(-1)
+    d2 = (sw.unsqueeze(0) * theta * theta).sum(-1) / den.unsqueeze(0)
+    tau = torch.nn.functional.softplus(log_temp.detach().float())
+    pre = -d2 / tau.unsqueeze(1)
+    gsig = sw.unsqueeze(0) * 2.0 * theta * (-1.0 / torch.sqrt(1.0 - sig_c * sig_c)) / den.view(1, -1, 1)
+    floor = 1e-9 if unnormalised else 1e-12
+    ok = (sig <= 1.0 - eps) & (sig > floor)
+    safe = sig.clamp_min(floor)
+    coef = torch.where(ok, gsig / (safe ** 3 if unnormalised else safe), torch.zeros_like(gsig))
+    return d2, pre, torch.softmax(pre, dim=1), coef
 
 
 def mix_tokens(layers, w):

@@ -654,6 +654,28 @@ def test_attention_bwd_matches_autograd(nat, B, T, H):
         assert float((got - want).abs().max()) < 4e-2 * float(want.abs().max()), name
 
 
+@pytest.mark.parametrize("E,L,D,unnorm", [(4, 12, 192, True), (4, 32, 768, False), (1, 1, 32, True)])
+def test_angle_weights_matches_the_torch_chain(nat, E, L, D, unnorm):
+    """fused acos / spectral weighting / softmax / backward-seed diagonal (layer_selector.py:100-108) against the torch
+    chain of the emulation, incl. clamped cosines (>= 1 - eps), rank-masked directions (sw = 0) and tiny cosines"""
+    from tests import _emul
+    g = torch.Generator().manual_seed(E * 100 + L)
+    sig = torch.rand(E, L, D, generator=g).sort(dim=-1, descending=True).values
+    sig[:, :, 0] = 1.0                                   # clamped: d(d2)/d(sigma) = 0 there
+    sig[:, :, 1] = 1.0 - 3e-8
+    sig[:, :, -3:] = torch.tensor([1e-7, 1e-11, 0.0])
+    sw = torch.rand(L, D, generator=g).sort(dim=-1, descending=True).values + 0.1
+    ranks = torch.randint(4, D, (L,), generator=g)
+    sw = sw * (torch.arange(D).unsqueeze(0) < ranks.unsqueeze(1))
+    lt = torch.linspace(-0.5, 0.8, E)
+    d2, pre, w, coef = nat.angle_weights(sig.cuda(), sw.cuda(), lt.cuda(), unnorm)
+    rd2, rpre, rw, rcoef = _emul.angle_weights(sig, sw, lt, unnorm)
+    assert torch.allclose(d2.cpu(), rd2, rtol=2e-6, atol=1e-7) and torch.allclose(pre.cpu(), rpre, rtol=2e-6, atol=1e-7)
+    assert torch.allclose(w.cpu(), rw, rtol=1e-5, atol=1e-7) and abs(float(w.sum(1).mean()) - 1.0) < 1e-6
+    assert torch.allclose(coef.cpu(), rcoef, rtol=5e-5, atol=1e-6 * float(rcoef.abs().max()))
+    assert float(coef[:, :, 0].abs().max()) == 0.0 and float(coef[:, :, -1].abs().max()) == 0.0
+
+
 def test_empty_batches_are_noops(nat):
     """zero-sized batches return without launching (every C-ABI entry checks for them first)"""
     dev = "cuda"

@@ -20,7 +20,7 @@ JACOBI_LDS_BYTES = 163840
 
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
-    "basd_mp_rank", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
+    "basd_mp_rank", "basd_angle_weights", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_gemm_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
 )
@@ -37,6 +37,7 @@ _SIGNATURES = {
     "basd_trinv_f64": (_P, _P, _P, _I, _I, _P, _P),
     "basd_jacobi_svd": (_P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _I, _P, _P),
     "basd_mp_rank": (_P, _I, _I, _I64, _I, _I, _P, _P, _P),
+    "basd_angle_weights": (_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P),
     "basd_mix_tokens": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
     "basd_procrustes_prep": (_P, _I, _I64, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P),
     "basd_mix_grad_dots": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
@@ -234,18 +235,31 @@ def _token_gram_wide(x: torch.Tensor, proj: torch.Tensor):
     return gram, z.sum(dim=0, dtype=torch.float64)
 
 
-def token_gram(x: torch.Tensor, proj: torch.Tensor, mirror: bool = True):
+def token_gram(x: torch.Tensor, proj: torch.Tensor, mirror: bool = True, out=None):
     """x [M, d_in] or [B, N, d_in] view (f32/bf16), proj [d_out, d_in] f32 ->
     gram [d_out, d_out] f64, colsum [d_out] f64.  ``mirror=False`` leaves the strict upper triangle
-    unspecified (the kernels fill lower tiles only; ``pchol`` reads nothing else)."""
+    unspecified (the kernels fill lower tiles only; ``pchol`` reads nothing else).
+    ``out`` = (gram, colsum) ZEROED fp64 buffers to accumulate into (e.g. slices of one per-step allocation: a
+    16-layer step otherwise spends 32 launches on zero-fills); requires ``mirror=False``."""
     _need_cuda(x, proj)
     if proj.shape[0] > 256 or proj.shape[0] % 16 or x.shape[-1] % 32:
-        return _token_gram_wide(x, proj.contiguous().float())
+        g, c = _token_gram_wide(x, proj.contiguous().float())
+        if out is not None:
+            out[0].copy_(g)
+            out[1].copy_(c)
+            return out
+        return g, c
     x, m, d_in, rpb, bstride = _token_view(x)
     proj = proj.contiguous().float()
     d_out = proj.shape[0]
-    gram = torch.zeros(d_out, d_out, dtype=torch.float64, device=x.device)
-    colsum = torch.zeros(d_out, dtype=torch.float64, device=x.device)
+    if out is not None:
+        assert not mirror
+        gram, colsum = out
+        assert gram.shape == (d_out, d_out) and colsum.shape == (d_out,) and gram.dtype == torch.float64
+        assert gram.is_contiguous() and colsum.is_contiguous()
+    else:
+        gram = torch.zeros(d_out, d_out, dtype=torch.float64, device=x.device)
+        colsum = torch.zeros(d_out, dtype=torch.float64, device=x.device)
     i64 = ctypes.c_int64
     if x.dtype == torch.bfloat16 and d_out in (32, 64, 128, 192) and d_in % 32 == 0:
         ps = split_bf16x3(proj)
@@ -319,6 +333,21 @@ def mp_rank(evals: torch.Tensor, rows: int, d: int, cap: int) -> torch.Tensor:
     _check(lib().basd_mp_rank(_ptr(evals), batch, n, ctypes.c_int64(rows), d, cap, _ptr(ranks),
                               _ptr(status_word(evals.device)), _stream()), "basd_mp_rank")
     return ranks
+
+
+def angle_weights(sigma: torch.Tensor, sw: torch.Tensor, log_temp: torch.Tensor, unnormalised: bool):
+    """sigma [E, L, D] cosines, sw [L, D] masked teacher singular values, log_temp [E] ->
+    (d2 [E, L], pre [E, L], weights [E, L], coef [E, L, D]) fp32; see basd_angle_weights."""
+    _need_cuda(sigma, sw, log_temp)
+    sigma, sw, log_temp = sigma.contiguous().float(), sw.contiguous().float(), log_temp.detach().contiguous().float()
+    e, l, d = sigma.shape
+    assert sw.shape == (l, d) and log_temp.numel() == e
+    d2 = torch.empty(e, l, dtype=torch.float32, device=sigma.device)
+    pre, wts = torch.empty_like(d2), torch.empty_like(d2)
+    coef = torch.empty(e, l, d, dtype=torch.float32, device=sigma.device)
+    _check(lib().basd_angle_weights(_ptr(sigma), _ptr(sw), _ptr(log_temp), e, l, d, int(unnormalised), _ptr(d2), _ptr(pre),
+                                    _ptr(wts), _ptr(coef), _stream()), "basd_angle_weights")
+    return d2, pre, wts, coef
 
 
 def _ptr_table(layers: list[torch.Tensor]):

@@ -215,6 +215,20 @@ def teacher_gram(tokens, proj_t):
     return get_ops().token_gram(tokens, proj_t, mirror=False)
 
 
+def _layer_grams(tokens, proj, grams=None):
+    """Uncentred Gram [n, D, D] and column sums [n, D] (fp64, lower triangles) of n token tensors: ONE zeroed
+    allocation for all layers, the per-layer kernels accumulate into its slices (no per-layer fills / stacks)."""
+    ops = get_ops()
+    if grams is not None:
+        return torch.stack([g for g, _ in grams]), torch.stack([c for _, c in grams])
+    n, d = len(tokens), proj.shape[0]
+    unc = torch.zeros(n, d, d, dtype=torch.float64, device=proj.device)
+    csum = torch.zeros(n, d, dtype=torch.float64, device=proj.device)
+    for i, x in enumerate(tokens):
+        ops.token_gram(x, proj, mirror=False, out=(unc[i], csum[i]))
+    return unc, csum
+
+
 def teacher_frames(teacher_tokens, proj_t, grams=None):
     """Teacher half of the selector (no gradient): per-layer Gram statistics -> MP ranks (device
     int32, no host sync) and rank-masked PCA frames.  Reference layer_selector.py:69-74, 133-138.
@@ -226,12 +240,9 @@ def teacher_frames(teacher_tokens, proj_t, grams=None):
     L = len(teacher_tokens)
     D = proj_t.shape[0]
     m_t = teacher_tokens[0].shape[0] * teacher_tokens[0].shape[1]
-    unc, cen = [], []
-    for i, x in enumerate(teacher_tokens):              # layer_selector.py:71-73, :134-136
-        g, c = grams[i] if grams is not None else ops.token_gram(x, proj_t, mirror=False)   # lower triangle
-        unc.append(g)
-        cen.append(g - torch.outer(c, c) / m_t)
-    sigma, u, _ = psd_eig(torch.stack(unc + cen), lower_only=True)
+    unc, csum = _layer_grams(teacher_tokens, proj_t, grams)              # layer_selector.py:71-73, :134-136
+    cen = unc - csum.unsqueeze(2) * csum.unsqueeze(1) / m_t              # centred Gram of every layer at once
+    sigma, u, _ = psd_eig(torch.cat([unc, cen]), lower_only=True)
     ranks = ops.mp_rank(sigma[:L] ** 2, m_t, D, D - 1)  # int32 [L], stays on device
     v_t, s_t = u[L:], sigma[L:]
     idx = torch.arange(D, device=proj_t.device)
@@ -247,7 +258,7 @@ def teacher_ranks(teacher_tokens, proj_t) -> torch.Tensor:
     ops = get_ops()
     D = proj_t.shape[0]
     m_t = teacher_tokens[0].shape[0] * teacher_tokens[0].shape[1]
-    unc = torch.stack([ops.token_gram(x, proj_t, mirror=False)[0] for x in teacher_tokens])
+    unc, _ = _layer_grams(teacher_tokens, proj_t)
     sigma, _, _ = psd_eig(unc, lower_only=True)
     return ops.mp_rank(sigma ** 2, m_t, D, D - 1)
 
@@ -258,13 +269,9 @@ def student_frames(student_tokens, proj_s):
     (sigma [E, D], v [E, D, D]).  No gradient flows through these tensors themselves -- the selector backward
     differentiates the eigen-decomposition analytically from them -- so a trainer may compute them ahead of the
     loss (reference layer_selector.py:84-92)."""
-    ops = get_ops()
-    mats = []
     m_s = student_tokens[0].shape[0] * student_tokens[0].shape[1]
-    for s in student_tokens:
-        g, c = ops.token_gram(s.detach(), proj_s, mirror=False)
-        mats.append(g - torch.outer(c, c) / m_s)
-    sigma_s, v_s, _ = psd_eig(torch.stack(mats), lower_only=True)
+    unc, csum = _layer_grams([s.detach() for s in student_tokens], proj_s)
+    sigma_s, v_s, _ = psd_eig(unc - csum.unsqueeze(2) * csum.unsqueeze(1) / m_s, lower_only=True)
     return sigma_s, v_s
 
 
@@ -292,27 +299,23 @@ class _SelectorWeightsFn(torch.autograd.Function):
             # only the leading k_j x k_j block of pair (i, j) is non-zero: sweep just that block
             sig, _ = ops.jacobi_svd(w, D, active=ranks.repeat(E), active_rows=True)   # cosines, descending
             sig = sig.view(E, L, D)
-            u_s = torch.where(sig.unsqueeze(-1) > 1e-20, w[:, :, :D].view(E, L, D, D) / sig.clamp_min(1e-20).unsqueeze(-1),
-                              torch.zeros(1, device=dev))               # [E, L, m, b]
+            vec = w[:, :, :D].view(E, L, D, D)                          # [E, L, m, b]: sigma_m u_m (un-normalised)
+            unnormalised = True
         else:
             # wide students (D_s = 384 / 768): cosines and left singular vectors from the blocked eigen-solver on
             # the fp64 Gram A_bar A_bar^T (zero rows / columns beyond k_j: the blocked Cholesky stops at the rank)
             ab = a_bar.reshape(E * L, D, D)
-            sig, u_s, _ = psd_eig(ops.bgemm_f64(ab, ab, trans_b=True, symmetric=True))
-            sig, u_s = sig.view(E, L, D), u_s.view(E, L, D, D)
-        sig_c = sig.clamp(max=1.0 - _EPS32)                         # layer_selector.py:100
-        theta = torch.acos(sig_c)
-        den = sw.sum(-1)                                            # [L]; 0 at rank 0 -> NaN like the reference
-        d2 = (sw.unsqueeze(0) * theta * theta).sum(-1) / den.unsqueeze(0)   # [E, L]
+            sig, vec, _ = psd_eig(ops.bgemm_f64(ab, ab, trans_b=True, symmetric=True))
+            sig, vec = sig.view(E, L, D), vec.view(E, L, D, D)
+            unnormalised = False
+        # acos / spectral weighting / softmax over layers and the diagonal of the backward seed in ONE kernel
+        # (layer_selector.py:100-108): d2 [E, L], pre = -d2 / tau, weights, coef [E, L, D]
+        d2, pre, wts, coef = ops.angle_weights(sig, sw, log_temp, unnormalised)
         tau = F.softplus(log_temp.float())
-        pre = -d2 / tau.unsqueeze(1)
-        wts = torch.softmax(pre, dim=1)
 
-        # seeds of the backward, per unit d(d2_ij): Phi = U diag(gsig / sig) U^T, T = A_full A_bar^T Phi
-        gsig = sw.unsqueeze(0) * 2.0 * theta * (-1.0 / torch.sqrt(1.0 - sig_c * sig_c)) / den.view(1, L, 1)
-        gsig = torch.where(sig <= 1.0 - _EPS32, gsig, torch.zeros_like(gsig))
-        ratio = torch.where(sig > 1e-12, gsig / sig.clamp_min(1e-12), torch.zeros_like(gsig))
-        phi = torch.einsum("ijmb,ijm,ijmc->ijbc", u_s, ratio, u_s)
+        # seeds of the backward, per unit d(d2_ij): Phi = U diag(gsig / sig) U^T = vec^T diag(coef) vec,
+        # T = A_full A_bar^T Phi
+        phi = torch.matmul((vec * coef.unsqueeze(-1)).transpose(-1, -2), vec)         # [E, L, b, c]
         t_seed = a_full @ a_bar.transpose(-1, -2) @ phi              # [E, L, D(b), D(a)]
         t_seed = t_seed * (1.0 - keep).view(1, L, D, 1)              # only b >= k_j (cross-subspace terms)
 
