@@ -19,6 +19,7 @@ def handles(t) -> bool:
     return True
 
 
+STATUS_NONCONVERGED, STATUS_NONFINITE, STATUS_RANK0 = 1, 2, 4
 _STATUS = torch.zeros(1, dtype=torch.int32)
 
 

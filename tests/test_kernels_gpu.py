@@ -256,6 +256,22 @@ def test_blocked_eigensolver_graded_spectra(nat, n, decay):
     assert float(res.norm(dim=-1).max()) < 2e-5           # lambda_max = 1; eigenvalues themselves are good to 2e-5 relative
 
 
+def test_blocked_eigensolver_flags_missing_convergence(nat, monkeypatch):
+    """with too few outer sweeps the device-side orthogonality check raises the NONCONVERGED bit"""
+    from basd_amd.losses import functional as BF, _ops
+    _ops.set_ops(None)
+    g = torch.Generator().manual_seed(1)
+    q, _ = torch.linalg.qr(torch.randn(1, 384, 384, generator=g, dtype=torch.float64))
+    a = ((q * (0.985 ** torch.arange(384, dtype=torch.float64)) ** 2) @ q.transpose(1, 2)).cuda()
+    monkeypatch.setattr(BF, "WIDE_DIRECT_SWEEPS", 2)
+    BF.psd_eig(a)
+    with pytest.raises(torch.linalg.LinAlgError, match="without converging"):
+        nat.check_status()
+    monkeypatch.setattr(BF, "WIDE_DIRECT_SWEEPS", 8)
+    BF.psd_eig(a)
+    nat.check_status()
+
+
 def test_blocked_eigensolver_rank_deficient(nat):
     """rank 150 in 384 dimensions: the blocked Cholesky stops at the rank, null directions come back as zero rows"""
     from basd_amd.losses import functional as BF, _ops

@@ -39,6 +39,7 @@ class BasdShapeError(NotImplementedError):
 # --------------------------------------------------------------------------- #
 WIDE_PANEL = 192          # widest eigenproblem of the LDS-resident Jacobi = panel of the blocked Cholesky
 WIDE_BLOCK = 96           # column block of the blocked Jacobi: a PAIR of blocks is one LDS-resident problem
+WIDE_COS_TOL = 1e-4      # columns of the blocked factor must end up orthogonal to this (else: NONCONVERGED flag)
 WIDE_DIRECT_SWEEPS = 8    # outer sweeps when a block pair fits the tall-column Jacobi kernel (n <= 384)
 _ROUND_CACHE: dict = {}
 
@@ -128,7 +129,15 @@ def _psd_eig_blocked(a64: torch.Tensor):
                 xp = xv[:, idx].reshape(b * (nblk // 2), 2 * WIDE_BLOCK, n_pad)
                 rot = _pair_rotation(ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True))
                 xv[:, idx] = ops.bgemm_f64(rot, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
-    nrm = x.double().square().sum(dim=-1).sqrt()                          # [b, n_pad] singular values = column norms
+    # the sweep counts are fixed (no host sync): verify on the device that the columns ARE orthogonal and raise the
+    # NONCONVERGED bit of the health word otherwise (surfaces as BasdLinAlgError at the next status check)
+    gram = ops.bgemm_f64(x, x, trans_b=True, symmetric=True)             # [b, n_pad, n_pad] = column Gram of X
+    nrm2 = torch.diagonal(gram, dim1=-2, dim2=-1)
+    scale = torch.rsqrt(nrm2.clamp_min(1e-300)) * (nrm2 > 0)
+    cosmax = (gram * scale.unsqueeze(-1) * scale.unsqueeze(-2) - torch.eye(n_pad, dtype=gram.dtype, device=gram.device)
+              ).abs().amax()
+    ops.status_word(x.device).bitwise_or_((cosmax > WIDE_COS_TOL).to(torch.int32) * ops.STATUS_NONCONVERGED)
+    nrm = nrm2.sqrt()                                                     # [b, n_pad] singular values = column norms
     order = torch.argsort(nrm, dim=-1, descending=True, stable=True)[:, :n]
     sigma = torch.gather(nrm, 1, order).float()
     cols = torch.gather(x, 1, order.unsqueeze(-1).expand(b, n, n_pad))[:, :, :n]
