@@ -23,8 +23,11 @@ def run_basd_loss(shape, inputs, gold, kind, device="cpu", token_dtype=torch.flo
     targets = (inputs["targets_hard"] if kind == "hard" else inputs["targets_soft"]).to(device)
     t_tok = {j: t.to(device=device, dtype=token_dtype) for j, t in inputs["teacher_tokens"].items()}
     t_att = {j: t.to(device) for j, t in inputs["teacher_attns"].items()}
+    from basd_amd.losses._ops import get_ops
+    get_ops().status_word(device).zero_()
     loss = mod(logits, targets, s_tok, t_tok, t_att)
     loss.backward()
+    get_ops().check_status()          # no kernel may have flagged non-convergence / non-finite values / rank 0
     sel = mod.layer_selector
     res = {
         "loss": loss.detach().cpu(), "ce": mod.last_terms["ce"].cpu(), "geo": mod.last_terms["geo"].cpu(),

@@ -15,3 +15,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+@pytest.fixture(autouse=True)
+def _clean_emulated_status_word():
+    """the emulated kernels' health word is sticky like the real one: every test starts from a clean one"""
+    from tests import _emul
+    _emul._STATUS.zero_()
+    yield

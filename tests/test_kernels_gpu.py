@@ -285,6 +285,7 @@ def test_blocked_eigensolver_rank_deficient(nat):
     assert float(s[:, 150:].abs().max()) <= 1e-6 * float(ref.max())
     live = u.abs().amax(-1) > 0
     assert live.sum(1).tolist() == [150, 150]
+    nat.check_status()                                  # zero columns must not trip the orthogonality check
 
 
 def test_status_word_flags_nonfinite_nonconverged_and_rank0(nat):

@@ -133,9 +133,9 @@ def _psd_eig_blocked(a64: torch.Tensor):
     # NONCONVERGED bit of the health word otherwise (surfaces as BasdLinAlgError at the next status check)
     gram = ops.bgemm_f64(x, x, trans_b=True, symmetric=True)             # [b, n_pad, n_pad] = column Gram of X
     nrm2 = torch.diagonal(gram, dim1=-2, dim2=-1)
-    scale = torch.rsqrt(nrm2.clamp_min(1e-300)) * (nrm2 > 0)
-    cosmax = (gram * scale.unsqueeze(-1) * scale.unsqueeze(-2) - torch.eye(n_pad, dtype=gram.dtype, device=gram.device)
-              ).abs().amax()
+    live = (nrm2 > 0).to(gram.dtype)                                      # columns dropped at the rank are exact zeros
+    scale = torch.rsqrt(nrm2.clamp_min(1e-300)) * live
+    cosmax = (gram * scale.unsqueeze(-1) * scale.unsqueeze(-2) - torch.diag_embed(live)).abs().amax()
     ops.status_word(x.device).bitwise_or_((cosmax > WIDE_COS_TOL).to(torch.int32) * ops.STATUS_NONCONVERGED)
     nrm = nrm2.sqrt()                                                     # [b, n_pad] singular values = column norms
     order = torch.argsort(nrm, dim=-1, descending=True, stable=True)[:, :n]
