@@ -202,6 +202,16 @@ int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int tr
 int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
                    int epilogue, void* stream);
 
+/* The trained student's MLP (timm Mlp: fc1 -> nn.GELU -> fc2, trainer.py:33 / :157) without a separate GELU pass:
+ *   fwd:  pre[m][n] = bf16(sum_k x[m][k] w[n][k] + bias[n])   (saved for backward),   y = bf16(gelu(pre))
+ *   bwd:  dpre[m][n] = bf16((sum_k dy[m][k] wt[n][k]) * gelu'(pre[m][n]))   with wt = fc2.weight^T  [N = hidden, K = out]
+ * exact-erf GELU and its derivative Phi(x) + x phi(x), evaluated in fp32 on the bf16-rounded pre-activation (what
+ * nn.GELU and its autograd see behind a bf16 nn.Linear).  Shapes as basd_gemm_bf16. */
+int basd_gemm_bf16_gelu_fwd(const void* x, const void* w, const void* bias, void* pre, void* y, int64_t M, int N,
+                            int K, void* stream);
+int basd_gemm_bf16_gelu_bwd(const void* dy, const void* wt, const void* pre, void* dpre, int64_t M, int N, int K,
+                            void* stream);
+
 /* ViT weight-gradient GEMM (backward of nn.Linear): dw[n][k] += sum_m dy[m][n] x[m][k],
  * db[n] += sum_m dy[m][n] (db may be NULL).  dy [M, N], x [M, K] bf16 row-major, dw [N, K] /
  * db [N] fp32, ACCUMULATED with atomics (caller zero-initialises or accumulates on purpose).
@@ -270,6 +280,12 @@ int basd_sf_adamw_step(float* y, const float* g, float* z, float* v, int64_t n, 
 
 /* y <- y + w (z - y): optimizer.train() / optimizer.eval() switch (trainer.py:180,184). */
 int basd_lerp(float* y, const float* z, int64_t n, float w, void* stream);
+
+/* Transposed bf16 images of n_entries weight matrices of the flat fp32 master buffer in one launch (the operands of
+ * the input-gradient GEMMs dX = dY W of trainer.py:157; refreshed once per step after the optimizer update).
+ * table: HOST array of n_entries x {src offset, dst offset, rows, cols} (int64, offsets in elements):
+ * out[dst + c * rows + r] = bf16(master[src + r * cols + c]). */
+int basd_transpose_bf16_table(const float* master, void* out, const int64_t* table, int n_entries, void* stream);
 
 #ifdef __cplusplus
 }

@@ -273,6 +273,23 @@ def gemm_bf16(x, w, bias=None, gelu=False):
     return y.to(torch.bfloat16)
 
 
+def transpose_table(master, out, table):
+    for src, dst, rows, cols in table:
+        out[dst:dst + rows * cols].view(cols, rows).copy_(master[src:src + rows * cols].view(rows, cols).t())
+
+
+def gemm_gelu_fwd(x, w, bias):
+    pre = gemm_bf16(x, w, bias)
+    return pre, torch.nn.functional.gelu(pre.float()).to(torch.bfloat16)
+
+
+def gemm_gelu_bwd(dy, wt, pre):
+    p = pre.float()
+    cdf = 0.5 * (1.0 + torch.erf(p * 0.7071067811865476))
+    pdf = torch.exp(-0.5 * p * p) * 0.3989422804014327
+    return ((dy.float() @ wt.float().t()) * (cdf + p * pdf)).to(torch.bfloat16)
+
+
 def wgrad_supported(n, k):
     return n % 64 == 0 and k % 64 == 0 and n >= 64 and k >= 64
 

@@ -384,6 +384,77 @@ def test_gemm_bf16_with_fused_epilogue(nat, M, N, K, gelu, bias):
         assert y3.shape == (4, M // 4, N) and torch.equal(y3.reshape(M, N), y)
 
 
+@pytest.mark.parametrize("M,hidden,d", [(50432, 768, 192), (25216, 1536, 384), (1000, 3072, 768), (300, 128, 64),
+                                        (517, 384, 192)])
+def test_gemm_bf16_gelu_training_pair(nat, M, hidden, d):
+    """fc1 + GELU in one launch (pre-activation saved) and fc2's input gradient times gelu'(pre) in one launch, against
+    the unfused fp32 arithmetic on the same bf16 inputs (ring kernel at hidden % 256 == 0, two-stage kernel otherwise;
+    ragged M)"""
+    g = torch.Generator().manual_seed(M + hidden + d)
+    x = torch.randn(M, d, generator=g).bfloat16().cuda()
+    w1 = (torch.randn(hidden, d, generator=g) / d ** 0.5).bfloat16().cuda()
+    b1 = torch.randn(hidden, generator=g).bfloat16().cuda()
+    pre, act = nat.gemm_gelu_fwd(x, w1, b1)
+    ref_pre = x.float() @ w1.float().t() + b1.float()
+    assert pre.shape == act.shape == (M, hidden) and pre.dtype == act.dtype == torch.bfloat16
+    assert float((pre.float() - ref_pre).abs().max()) <= 6e-3 * float(ref_pre.abs().max())
+    # the activation is the GELU of the ROUNDED pre-activation (what nn.GELU sees behind a bf16 nn.Linear)
+    ref_act = torch.nn.functional.gelu(pre.float())
+    assert float((act.float() - ref_act).abs().max()) <= 4.1e-3 * float(ref_act.abs().max())
+    assert torch.equal(pre, nat.gemm_bf16(x, w1, b1))                 # same accumulation, same rounding
+    # backward: dY [M, d] through fc2 (weight [d, hidden]) and the GELU
+    dy = (torch.randn(M, d, generator=g) * 0.1).bfloat16().cuda()
+    w2 = (torch.randn(d, hidden, generator=g) / hidden ** 0.5).bfloat16().cuda()
+    dpre = nat.gemm_gelu_bwd(dy, w2.t().contiguous(), pre)
+    p = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(p).backward(dy.float() @ w2.float())
+    ref = p.grad
+    err = (dpre.float() - ref).abs()
+    assert dpre.shape == (M, hidden)
+    assert float(err.max()) <= 6e-3 * float(ref.abs().max())
+    assert float((err / (ref.abs() + 1e-2 * float(ref.abs().max()))).max()) < 1.2e-2
+
+
+def test_transpose_table_all_weights_in_one_launch(nat):
+    """bf16 W^T images of many matrices of the flat fp32 master buffer (ragged shapes, > 64 entries = two launches)"""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(192, 576), (576, 192), (768, 192), (192, 768), (33, 70), (1, 5), (64, 64)] * 10
+    table, src, dst = [], 0, 0
+    for r, c in shapes:
+        table.append((src, dst, r, c))
+        src += (r * c + 63) // 64 * 64
+        dst += (r * c + 63) // 64 * 64
+    master = torch.randn(src, generator=g).cuda()
+    out = torch.zeros(dst, dtype=torch.bfloat16, device="cuda")
+    nat.transpose_table(master, out, table)
+    for s0, d0, r, c in table:
+        want = master[s0:s0 + r * c].view(r, c).t().to(torch.bfloat16)
+        assert torch.equal(out[d0:d0 + r * c].view(c, r), want)
+
+
+def test_fused_mlp_matches_the_unfused_layers():
+    """timm Mlp of a trained block: fused path (GELU inside the GEMM epilogues) against fc1 -> nn.GELU -> fc2 on the
+    per-layer kernels: outputs and all five gradients"""
+    from basd_amd.models.vit import Mlp
+    from basd_amd.models import linear as lin_mod
+    torch.manual_seed(3)
+    mlp = Mlp(192, 768).cuda()
+    x = torch.randn(8, 197, 192, device="cuda").bfloat16().requires_grad_(True)
+    g = torch.randn(8, 197, 192, device="cuda").bfloat16() * 0.1
+    assert lin_mod.fused_mlp_ok(x, mlp.fc1, mlp.fc2)
+    y = mlp(x)
+    y.backward(g)
+    got = [y.detach().float(), x.grad.float()] + [p.grad.clone() for p in mlp.parameters()]
+    x.grad = None
+    for p in mlp.parameters():
+        p.grad = None
+    y2 = mlp.fc2(mlp.act(mlp.fc1(x)))
+    y2.backward(g)
+    want = [y2.detach().float(), x.grad.float()] + [p.grad for p in mlp.parameters()]
+    for a, b in zip(got, want):
+        assert float((a - b).norm() / b.norm()) < 6e-3, float((a - b).norm() / b.norm())
+
+
 @pytest.mark.parametrize("M,N,K", [(50432, 576, 192), (1000, 192, 768), (333, 64, 64), (4096, 768, 192), (777, 128, 128)])
 def test_wgrad_bf16(nat, M, N, K):
     g = torch.Generator().manual_seed(M + N)

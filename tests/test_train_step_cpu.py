@@ -120,6 +120,79 @@ def test_fused_residual_layernorm_blocks_equal_the_plain_blocks():
     assert abs(float(g1.norm() / g0.norm()) - 1.0) < 2e-2
 
 
+def test_fused_mlp_equals_the_plain_layers():
+    """trained Mlp: GELU forward / backward inside the GEMM epilogues (one autograd node for fc1 -> GELU -> fc2) against
+    the three separate nodes -- same emulated kernels, so the gradients agree to bf16 rounding of the intermediates"""
+    from basd_amd.models import linear as lin_mod
+    from basd_amd.models.vit import Mlp
+    torch.manual_seed(0)
+    mlp = Mlp(192, 768)
+    x = torch.randn(2, 65, 192).bfloat16().requires_grad_(True)
+    g = torch.randn(2, 65, 192).bfloat16() * 0.1
+    assert lin_mod.fused_mlp_ok(x, mlp.fc1, mlp.fc2)
+    y = mlp(x)
+    assert type(y.grad_fn).__name__ == "_MlpFnBackward"
+    y.backward(g)
+    got = [y.detach().float(), x.grad.float()] + [p.grad.clone() for p in mlp.parameters()]
+    x.grad = None
+    mlp.zero_grad()
+    y2 = mlp.fc2(mlp.act(mlp.fc1(x)))
+    y2.backward(g)
+    want = [y2.detach().float(), x.grad.float()] + [p.grad for p in mlp.parameters()]
+    for a, b in zip(got, want):
+        assert float((a - b).norm() / b.norm()) < 4e-3
+
+
+def test_mixup_cutmix_blends_with_the_previous_sample_in_one_pass():
+    """on-device RandomChoice([MixUp, CutMix]) (reference trainer.py:89-92): partner = the batch rolled by one; the
+    single-pass form (shifted slices, written into a given buffer) must equal the definition with the rolled batch"""
+    from basd_amd.training.mixup import mixup_cutmix
+    seen = set()
+    for seed in range(12):
+        torch.manual_seed(seed)
+        x = torch.randn(5, 3, 16, 16)
+        y = torch.arange(5)
+        out, out_t = torch.empty_like(x), torch.empty(5, 7)
+        mixed, tgt = mixup_cutmix(x, y, 7, out=out, out_targets=out_t)
+        assert mixed is out and tgt is out_t
+        lam = float(tgt[2, 2])
+        onehot = torch.nn.functional.one_hot(y, 7).float()
+        torch.testing.assert_close(tgt, lam * onehot + (1 - lam) * onehot.roll(1, 0))
+        rolled = x.roll(1, 0)
+        if torch.allclose(mixed, lam * x + (1 - lam) * rolled, atol=1e-6):
+            seen.add("mixup")
+        else:
+            from_partner = mixed == rolled
+            assert bool(((mixed == x) | from_partner).all())
+            assert abs(float(from_partner[:, 0].float().mean()) - (1 - lam)) < 1e-6
+            seen.add("cutmix")
+    assert seen == {"mixup", "cutmix"}
+
+
+def test_patch_embedding_on_the_gemm_kernels_equals_the_convolution():
+    """PatchEmbed: unfold + GEMM on the (emulated) kernels == the stride-p convolution the reference's timm model runs;
+    trained (autocast, fp32 master weight, gradient through the matrix view) and frozen bf16 (teacher)"""
+    from basd_amd.models.vit import PatchEmbed
+    torch.manual_seed(0)
+    pe = PatchEmbed(64, 16, 3, 192)
+    x = torch.randn(2, 3, 64, 64)
+    want = torch.nn.functional.conv2d(x, pe.proj.weight, pe.proj.bias, stride=16).flatten(2).transpose(1, 2)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y = pe(x)
+    assert y.dtype == torch.bfloat16 and type(y.grad_fn).__name__ == "_LinearFnBackward"
+    torch.testing.assert_close(y.float(), want, atol=3e-2, rtol=3e-2)
+    g = torch.randn_like(want)
+    y.backward(g.bfloat16())
+    gw, gb = torch.autograd.grad(want, [pe.proj.weight, pe.proj.bias], g)
+    assert pe.proj.weight.grad.shape == pe.proj.weight.shape
+    assert float((pe.proj.weight.grad - gw).norm() / gw.norm()) < 1e-2
+    assert float((pe.proj.bias.grad - gb).norm() / gb.norm()) < 1e-2
+    frozen = PatchEmbed(64, 16, 3, 192).to(torch.bfloat16)
+    frozen.load_state_dict(pe.state_dict())
+    with torch.no_grad():
+        torch.testing.assert_close(frozen(x.bfloat16()).float(), want, atol=3e-2, rtol=3e-2)
+
+
 def test_layerscale_teacher_is_folded_exactly():
     """DINOv2-style teacher (the reference's default): LayerScale folded into proj / fc2 at load time == the unfolded
     model, and the loaded teacher has no LayerScale left (so its blocks take the fused path)"""

@@ -21,7 +21,8 @@ JACOBI_LDS_BYTES = 163840
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_angle_weights", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
-    "basd_sf_adamw_step", "basd_lerp", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_gemm_bf16", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
+    "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_gemm_bf16",
+    "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
 )
 
@@ -41,9 +42,12 @@ _SIGNATURES = {
     "basd_mix_tokens": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
     "basd_procrustes_prep": (_P, _I, _I64, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P),
     "basd_mix_grad_dots": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
+    "basd_transpose_bf16_table": (_P, _P, _P, _I, _P),
     "basd_bgemm_f64": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P),
     "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
     "basd_gemm_bf16": (_P, _P, _P, _P, _I64, _I, _I, _I, _P),
+    "basd_gemm_bf16_gelu_fwd": (_P, _P, _P, _P, _P, _I64, _I, _I, _P),
+    "basd_gemm_bf16_gelu_bwd": (_P, _P, _P, _P, _I64, _I, _I, _P),
     "basd_layernorm_fwd_bf16": (_P, _P, _P, _I64, _I, _F, _P, _P, _P, _P),
     "basd_add_layernorm_fwd_bf16": (_P, _P, _P, _P, _I64, _I, _F, _P, _P, _P, _P, _P, _I, _P),
     "basd_layernorm_bwd_bf16": (_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _I, _P),
@@ -463,6 +467,20 @@ def lerp_(y, z, w: float) -> None:
     _check(lib().basd_lerp(_ptr(y), _ptr(z), ctypes.c_int64(y.numel()), ctypes.c_float(w), _stream()), "basd_lerp")
 
 
+def transpose_table(master: torch.Tensor, out: torch.Tensor, table) -> None:
+    """table: list of (src offset, dst offset, rows, cols); out[dst + c rows + r] = bf16(master[src + r cols + c]) for
+    every entry, one launch (weights^T for the input-gradient GEMMs, refreshed once per step)."""
+    _need_cuda(master, out)
+    assert master.dtype == torch.float32 and out.dtype == torch.bfloat16
+    if not table:
+        return
+    for src, dst, rows, cols in table:
+        assert 0 <= src and src + rows * cols <= master.numel() and 0 <= dst and dst + rows * cols <= out.numel()
+    flat = (ctypes.c_int64 * (4 * len(table)))(*[int(v) for e in table for v in e])
+    _check(lib().basd_transpose_bf16_table(_ptr(master), _ptr(out), ctypes.cast(flat, ctypes.c_void_p), len(table),
+                                           _stream()), "basd_transpose_bf16_table")
+
+
 def bgemm_f64(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
               out_dtype=torch.float64, symmetric: bool = False) -> torch.Tensor:
     """Batched op(a) @ op(b) with fp64 accumulation; a, b [batch, r, c] fp32/fp64 contiguous."""
@@ -513,6 +531,42 @@ def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None
     _check(lib().basd_gemm_bf16(_ptr(x2), _ptr(w), _ptr(None if bias is None else bias.contiguous()), _ptr(y),
                                 ctypes.c_int64(x2.shape[0]), n, k, epi, _stream()), "basd_gemm_bf16")
     return y.view(*x.shape[:-1], n)
+
+
+def gemm_gelu_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None):
+    """x [..., K], w [N, K], bias [N] | None (bf16) -> (pre, act) [..., N] bf16: pre = x w^T + bias rounded to bf16,
+    act = gelu(pre) -- fc1 + nn.GELU of a trained block in one launch, ``pre`` saved for ``gemm_gelu_bwd``."""
+    _need_cuda(x, w, bias)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.bfloat16)
+    k, n = x.shape[-1], w.shape[0]
+    assert w.shape[1] == k and gemm_supported(n, k), (tuple(w.shape), k)
+    x2 = x.reshape(-1, k)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    pre = torch.empty(x2.shape[0], n, dtype=torch.bfloat16, device=x.device)
+    act = torch.empty_like(pre)
+    _check(lib().basd_gemm_bf16_gelu_fwd(_ptr(x2), _ptr(w.contiguous()), _ptr(None if bias is None else bias.contiguous()),
+                                         _ptr(pre), _ptr(act), ctypes.c_int64(x2.shape[0]), n, k, _stream()),
+           "basd_gemm_bf16_gelu_fwd")
+    return pre.view(*x.shape[:-1], n), act.view(*x.shape[:-1], n)
+
+
+def gemm_gelu_bwd(dy: torch.Tensor, wt: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    """dy [..., K], wt [N, K] (= fc2.weight^T, contiguous), pre [..., N] (bf16) -> (dy wt^T) * gelu'(pre) [..., N] bf16:
+    the input gradient of fc2 and the GELU backward in one launch."""
+    _need_cuda(dy, wt, pre)
+    assert dy.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and pre.dtype == torch.bfloat16
+    k, n = dy.shape[-1], wt.shape[0]
+    assert wt.shape[1] == k and pre.shape[-1] == n and gemm_supported(n, k), (tuple(wt.shape), tuple(pre.shape), k)
+    dy2 = dy.reshape(-1, k)
+    if not dy2.is_contiguous():
+        dy2 = dy2.contiguous()
+    pre2 = pre.reshape(-1, n)
+    assert pre2.is_contiguous() and pre2.shape[0] == dy2.shape[0]
+    out = torch.empty_like(pre2)
+    _check(lib().basd_gemm_bf16_gelu_bwd(_ptr(dy2), _ptr(wt.contiguous()), _ptr(pre2), _ptr(out),
+                                         ctypes.c_int64(dy2.shape[0]), n, k, _stream()), "basd_gemm_bf16_gelu_bwd")
+    return out.view(*pre.shape)
 
 
 def wgrad_supported(n: int, k: int) -> bool:

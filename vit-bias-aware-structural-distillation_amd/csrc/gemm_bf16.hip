@@ -40,6 +40,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// d/dx of the exact-erf GELU: Phi(x) + x phi(x); exp(-x^2 / 2) is the exponential the erf evaluation already needs
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
+                              0.254829592f);
+  const float e = __expf(-z * z);
+  const float erf_abs = fmaf(-poly, e, 1.0f);
+  return fmaf(x * 0.3989422804014327f, e, 0.5f * (1.0f + copysignf(erf_abs, x)));
+}
+
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
   return __builtin_bit_cast(unsigned short, (__bf16)v);
 }
@@ -52,52 +63,84 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
 // them out as 16 bytes per lane, whole 128-byte (BN = 256) row segments per 8 lanes.
 template <int BN, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(gf32x4 (&acc)[NT][8], unsigned char* lds, const unsigned short* bias,
-                                              unsigned short* Y, int M, int N, int m0, int n0, int wm, int wn, int lane,
-                                              int wave) {
+                                              unsigned short* aux, unsigned short* Y, int M, int N, int m0, int n0,
+                                              int wm, int wn, int lane, int wave) {
   constexpr int WN = BN / 4;                       // columns of a wave
   constexpr int ROWB = WN * 2 + 16;                // LDS row stride in bytes
   constexpr int CH = WN * 2 / 16;                  // 16-byte chunks per row
   unsigned char* region = lds + wave * (128 * ROWB);
+  const size_t tile_off = (size_t)(m0 + wm * 128) * N + n0 + wn * WN;
+  auto flush = [&](unsigned short* dst) {          // region -> global, 16 bytes per lane along the rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2 * CH; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item / CH, ch = item - row * CH;
+      const uint4 v = *reinterpret_cast<const uint4*>(region + row * ROWB + ch * 16);
+      if (m0 + wm * 128 + row < M) *reinterpret_cast<uint4*>(dst + tile_off + (size_t)row * N + ch * 8) = v;
+    }
+  };
   __builtin_amdgcn_s_barrier();                    // every wave is done with the operand ring
+  if (EPI == 4) {                                  // the saved pre-activation tile comes in the way the result goes out
+#pragma unroll
+    for (int it = 0; it < 2 * CH; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item / CH, ch = item - row * CH;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m0 + wm * 128 + row < M) v = *reinterpret_cast<const uint4*>(aux + tile_off + (size_t)row * N + ch * 8);
+      *reinterpret_cast<uint4*>(region + row * ROWB + ch * 16) = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // wave-private region: no barrier
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int nl = i * 16 + 4 * (lane >> 4);       // local column of this lane's 4 values
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI >= 1 && bias != nullptr) {
+    if ((EPI == 1 || EPI == 2 || EPI == 3) && bias != nullptr) {
       const gu16x4 b4 = *reinterpret_cast<const gu16x4*>(bias + n0 + wn * WN + nl);
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = bf16_bits_to_f32(b4[r]);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      gu16x4 o;
+      gu16x4* cell = reinterpret_cast<gu16x4*>(region + (j * 16 + (lane & 15)) * ROWB + nl * 2);
+      gu16x4 o, pre;
+      if (EPI == 4) pre = *cell;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[r];
         if (EPI == 2) v = gelu_erf(v);
+        if (EPI == 4) v *= gelu_erf_grad(bf16_bits_to_f32(pre[r]));
         o[r] = f32_to_bf16_bits(v);
       }
-      *reinterpret_cast<gu16x4*>(region + (j * 16 + (lane & 15)) * ROWB + nl * 2) = o;
+      *cell = o;
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  unsigned short* ybase = Y + (size_t)(m0 + wm * 128) * N + n0 + wn * WN;
+  if (EPI == 3) {                                  // pre-activation out (saved for backward), then GELU of the ROUNDED
+    flush(aux);                                    // value in place (what nn.GELU sees after a bf16 nn.Linear)
 #pragma unroll
-  for (int it = 0; it < 2 * CH; ++it) {
-    const int item = it * 64 + lane;
-    const int row = item / CH, ch = item - row * CH;
-    const uint4 v = *reinterpret_cast<const uint4*>(region + row * ROWB + ch * 16);
-    if (m0 + wm * 128 + row < M) *reinterpret_cast<uint4*>(ybase + (size_t)row * N + ch * 8) = v;
+    for (int i = 0; i < NT; ++i) {
+      const int nl = i * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gu16x4* cell = reinterpret_cast<gu16x4*>(region + (j * 16 + (lane & 15)) * ROWB + nl * 2);
+        gu16x4 p = *cell;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = f32_to_bf16_bits(gelu_erf(bf16_bits_to_f32(p[r])));
+        *cell = p;
+      }
+    }
   }
+  flush(Y);
 }
 
-// EPI: 0 = none, 1 = + bias, 2 = gelu(+ bias)
+// EPI: 0 = none, 1 = + bias, 2 = gelu(+ bias), 3 = aux <- (+ bias), y <- gelu(aux), 4 = y <- acc * gelu'(aux)
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel(const unsigned short* __restrict__ X,
                                                            const unsigned short* __restrict__ W,
                                                            const unsigned short* __restrict__ bias,
-                                                           unsigned short* __restrict__ Y, int M, int N, int K,
-                                                           int tiles_n, int mblocks) {
+                                                           unsigned short* aux, unsigned short* __restrict__ Y,
+                                                           int M, int N, int K, int tiles_n, int mblocks) {
   extern __shared__ __align__(16) unsigned char g_lds[];
   constexpr int A_BYTES = GBM * GBK * 2;          // 32 KiB
   constexpr int B_BYTES = BN * GBK * 2;
@@ -204,7 +247,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel(const unsigned short*
   for (int t = 0; t + 1 < nk; ++t) k_step(t, std::true_type{});
   k_step(nk - 1, std::false_type{});
 
-  gemm_epilogue<BN, NT, EPI>(acc, g_lds, bias, Y, M, N, m0, n0, wm, wn, lane, wave);
+  gemm_epilogue<BN, NT, EPI>(acc, g_lds, bias, aux, Y, M, N, m0, n0, wm, wn, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -220,8 +263,8 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const unsigned short* __restrict__ X,
                                                              const unsigned short* __restrict__ W,
                                                              const unsigned short* __restrict__ bias,
-                                                             unsigned short* __restrict__ Y, int M, int N, int K,
-                                                             int tiles_n, int mblocks) {
+                                                             unsigned short* aux, unsigned short* __restrict__ Y,
+                                                             int M, int N, int K, int tiles_n, int mblocks) {
   extern __shared__ __align__(16) unsigned char g_lds[];
   constexpr int BN = 256, NT = 4, UNIT = 32768, NSLOT = 5;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -316,49 +359,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const unsigned shor
     k_step(t, std::false_type{});
   }
 
-  gemm_epilogue<BN, NT, EPI>(acc, g_lds, bias, Y, M, N, m0, n0, wm, wn, lane, wave);
+  gemm_epilogue<BN, NT, EPI>(acc, g_lds, bias, aux, Y, M, N, m0, n0, wm, wn, lane, wave);
 }
 
 template <int EPI>
-static void launch_gemm_ring(const void* x, const void* w, const void* bias, void* y, int M, int N, int K,
+static void launch_gemm_ring(const void* x, const void* w, const void* bias, void* aux, void* y, int M, int N, int K,
                              hipStream_t st) {
   const int tiles_n = N / 256, mblocks = (M + GBM - 1) / GBM;
   const int groups = (mblocks + 7) / 8;
   allow_full_lds((const void*)gemm_bf16_ring_kernel<EPI>);
   hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3(groups * tiles_n * 8), dim3(512), 5 * 32768, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
-                     (unsigned short*)y, M, N, K, tiles_n, mblocks);
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks);
 }
 
 template <int BN, int EPI>
-static void launch_gemm(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, hipStream_t st) {
+static void launch_gemm(const void* x, const void* w, const void* bias, void* aux, void* y, int M, int N, int K,
+                        hipStream_t st) {
   const int tiles_n = N / BN, mblocks = (M + GBM - 1) / GBM;
   const int groups = (mblocks + 7) / 8;
   const size_t lds = 2 * (size_t)(GBM * GBK * 2 + BN * GBK * 2);
   allow_full_lds((const void*)gemm_bf16_nt_kernel<BN, EPI>);
   hipLaunchKernelGGL((gemm_bf16_nt_kernel<BN, EPI>), dim3(groups * tiles_n * 8), dim3(512), lds, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
-                     (unsigned short*)y, M, N, K, tiles_n, mblocks);
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks);
 }
 
 }  // namespace basd
 
-extern "C" int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
-                              int epilogue, void* stream) {
+static int gemm_dispatch(const void* x, const void* w, const void* bias, void* aux, void* y, int64_t M, int N, int K,
+                         int epilogue, void* stream, const char* what) {
   using namespace basd;
   if (M <= 0) return BASD_OK;
-  if (M > 0x7fffff00LL) return fail(BASD_ERR_SHAPE, "gemm_bf16: M = %lld too large", (long long)M);
+  if (M > 0x7fffff00LL) return fail(BASD_ERR_SHAPE, "%s: M = %lld too large", what, (long long)M);
   if (K % GBK || K < GBK || (N % 256 && N % 192 && N % 128) || N < 128)
-    return fail(BASD_ERR_SHAPE, "gemm_bf16: need K %% 64 == 0 and N a multiple of 256, 192 or 128 (got N=%d K=%d)", N, K);
-  if (epilogue < 0 || epilogue > 2) return fail(BASD_ERR_SHAPE, "gemm_bf16: epilogue %d not in {0, 1, 2}", epilogue);
-  if (epilogue >= 1 && bias == nullptr && epilogue == 1) epilogue = 0;
+    return fail(BASD_ERR_SHAPE, "%s: need K %% 64 == 0 and N a multiple of 256, 192 or 128 (got N=%d K=%d)", what, N, K);
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)M;
-#define BASD_GEMM(BN)                                                  \
+#define BASD_GEMM_EPI(LAUNCH)                                          \
   do {                                                                 \
-    if (epilogue == 0) launch_gemm<BN, 0>(x, w, bias, y, m, N, K, st); \
-    else if (epilogue == 1) launch_gemm<BN, 1>(x, w, bias, y, m, N, K, st); \
-    else launch_gemm<BN, 2>(x, w, bias, y, m, N, K, st);               \
+    switch (epilogue) {                                                \
+      case 0: LAUNCH(0); break;                                        \
+      case 1: LAUNCH(1); break;                                        \
+      case 2: LAUNCH(2); break;                                        \
+      case 3: LAUNCH(3); break;                                        \
+      default: LAUNCH(4); break;                                       \
+    }                                                                  \
   } while (0)
   // tile width: among the widths that divide N, the one whose tile count fills the 256 CUs best in whole rounds
   // (fc2 of ViT-B: 197 x 3 tiles of 256 columns = 2.3 rounds -> 3; 197 x 6 tiles of 128 = 4.6 -> 5: 77 % -> 92 %);
@@ -374,11 +420,38 @@ extern "C" int basd_gemm_bf16(const void* x, const void* w, const void* bias, vo
                                                        // two-stage tiles run at 0.6 - 0.8 of the ring kernel's rate
     if (eff > best_eff + 1e-9) { best_eff = eff; best_bn = bn; }
   }
-  if (best_bn == 256) {
-    if (epilogue == 0) launch_gemm_ring<0>(x, w, bias, y, m, N, K, st);
-    else if (epilogue == 1) launch_gemm_ring<1>(x, w, bias, y, m, N, K, st);
-    else launch_gemm_ring<2>(x, w, bias, y, m, N, K, st);
-  } else if (best_bn == 192) BASD_GEMM(192); else BASD_GEMM(128);
-#undef BASD_GEMM
-  return check_launch("gemm_bf16");
+#define BASD_RING(E) launch_gemm_ring<E>(x, w, bias, aux, y, m, N, K, st)
+#define BASD_NT192(E) launch_gemm<192, E>(x, w, bias, aux, y, m, N, K, st)
+#define BASD_NT128(E) launch_gemm<128, E>(x, w, bias, aux, y, m, N, K, st)
+  if (best_bn == 256) BASD_GEMM_EPI(BASD_RING);
+  else if (best_bn == 192) BASD_GEMM_EPI(BASD_NT192);
+  else BASD_GEMM_EPI(BASD_NT128);
+#undef BASD_RING
+#undef BASD_NT192
+#undef BASD_NT128
+#undef BASD_GEMM_EPI
+  return check_launch(what);
+}
+
+extern "C" int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
+                              int epilogue, void* stream) {
+  using namespace basd;
+  if (epilogue < 0 || epilogue > 2) return fail(BASD_ERR_SHAPE, "gemm_bf16: epilogue %d not in {0, 1, 2}", epilogue);
+  if (epilogue == 1 && bias == nullptr) epilogue = 0;
+  return gemm_dispatch(x, w, bias, nullptr, y, M, N, K, epilogue, stream, "gemm_bf16");
+}
+
+extern "C" int basd_gemm_bf16_gelu_fwd(const void* x, const void* w, const void* bias, void* pre, void* y, int64_t M,
+                                       int N, int K, void* stream) {
+  using namespace basd;
+  if (M > 0 && (pre == nullptr || y == nullptr)) return fail(BASD_ERR_SHAPE, "gemm_bf16_gelu_fwd: pre and y are required");
+  return gemm_dispatch(x, w, bias, pre, y, M, N, K, 3, stream, "gemm_bf16_gelu_fwd");
+}
+
+extern "C" int basd_gemm_bf16_gelu_bwd(const void* dy, const void* wt, const void* pre, void* dpre, int64_t M, int N,
+                                       int K, void* stream) {
+  using namespace basd;
+  if (M > 0 && (pre == nullptr || dpre == nullptr))
+    return fail(BASD_ERR_SHAPE, "gemm_bf16_gelu_bwd: pre and dpre are required");
+  return gemm_dispatch(dy, wt, nullptr, const_cast<void*>(pre), dpre, M, N, K, 4, stream, "gemm_bf16_gelu_bwd");
 }

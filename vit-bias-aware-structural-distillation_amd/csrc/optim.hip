@@ -56,7 +56,67 @@ __global__ __launch_bounds__(256) void lerp_kernel(float* __restrict__ y, const 
     y[i] = y[i] + w * (z[i] - y[i]);
 }
 
+// Transposed bf16 images of the weight matrices for the input-gradient GEMMs (dX = dY W runs as the "NT" kernel on
+// W^T): all matrices of the model in ONE launch, read from the fp32 master buffer.  A 32 x 32 tile per workgroup goes
+// through LDS (padded rows) so that both the fp32 reads and the bf16 writes are along rows.
+constexpr int TT_MAX = 64;
+struct TransposeTable {
+  int64_t src[TT_MAX], dst[TT_MAX];
+  int rows[TT_MAX], cols[TT_MAX], tile0[TT_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void transpose_table_kernel(const float* __restrict__ master,
+                                                              unsigned short* __restrict__ out, TransposeTable t) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int e = 0;
+  while (e + 1 < t.n && b >= t.tile0[e + 1]) ++e;            // <= 64 entries, wave-uniform
+  const int rows = t.rows[e], cols = t.cols[e];
+  const int tiles_c = (cols + 31) / 32;
+  const int local = b - t.tile0[e];
+  const int r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 32;
+  const float* src = master + t.src[e];
+  unsigned short* dst = out + t.dst[e];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;                // output row = source column
+    if (c < cols && r < rows) dst[(int64_t)c * rows + r] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][ty + 8 * i]);
+  }
+}
+
 }  // namespace basd
+
+extern "C" int basd_transpose_bf16_table(const float* master, void* out, const int64_t* table, int n_entries,
+                                         void* stream) {
+  using namespace basd;
+  if (n_entries < 0) return fail(BASD_ERR_SHAPE, "transpose_bf16_table: n_entries = %d", n_entries);
+  for (int base = 0; base < n_entries; base += TT_MAX) {
+    TransposeTable t;
+    t.n = n_entries - base < TT_MAX ? n_entries - base : TT_MAX;
+    int tiles = 0;
+    for (int i = 0; i < t.n; ++i) {
+      const int64_t* e = table + 4 * (int64_t)(base + i);
+      if (e[2] <= 0 || e[3] <= 0 || e[2] > 0x7fffffff || e[3] > 0x7fffffff)
+        return fail(BASD_ERR_SHAPE, "transpose_bf16_table: entry %d has shape %lld x %lld", base + i, (long long)e[2],
+                    (long long)e[3]);
+      t.src[i] = e[0]; t.dst[i] = e[1]; t.rows[i] = (int)e[2]; t.cols[i] = (int)e[3];
+      t.tile0[i] = tiles;
+      tiles += (int)((e[2] + 31) / 32) * (int)((e[3] + 31) / 32);
+    }
+    t.tile0[t.n] = tiles;
+    hipLaunchKernelGGL(transpose_table_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, master,
+                       (unsigned short*)out, t);
+  }
+  return check_launch("transpose_bf16_table");
+}
 
 extern "C" int basd_sf_adamw_step(float* y, const float* g, float* z, float* v, int64_t n, double lr,
                                   double beta1, double beta2, double eps, double weight_decay, double ckp1,

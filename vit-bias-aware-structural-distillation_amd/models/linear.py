@@ -15,20 +15,43 @@ import torch.nn.functional as F
 from ..losses._ops import get_ops
 
 
+def _bf16_of(p):
+    """bf16 image of a parameter: FlatParams.refresh_bf16() casts every parameter with ONE kernel per step; fall back
+    to a per-call cast when the module is used outside the trainer"""
+    if p is None:
+        return None
+    p16 = getattr(p, "_basd_bf16", None)
+    return p16 if p16 is not None else p.to(torch.bfloat16)
+
+
+def _bf16_transposed(weight, w16):
+    """bf16 W^T for the input-gradient GEMM: the image FlatParams keeps (one launch per step for all layers), else a
+    per-call transpose (<= 0.6 M elements)"""
+    wt = getattr(weight, "_basd_bf16_t", None)
+    return wt if wt is not None else w16.t().contiguous()
+
+
+def _weight_grads(weight, bias, dy2, x2):
+    """dW = dY^T X, db = sum dY.  With gradient sinks (views of the flat fp32 gradient buffer) the kernel accumulates
+    straight into them -- no temporary, no AccumulateGrad add kernel -- and the data-parallel reducer is told that the
+    slots are ready; (None, None) is returned to autograd then."""
+    sink_w = getattr(weight, "_basd_grad", None)
+    sink_b = getattr(bias, "_basd_grad", None) if bias is not None else None
+    if sink_w is not None and (bias is None or sink_b is not None):
+        get_ops().wgrad_bf16(dy2, x2, need_bias=bias is not None, out_w=sink_w, out_b=sink_b)
+        for p in (weight, bias):
+            ready = getattr(p, "_basd_ready", None) if p is not None else None
+            if ready is not None:
+                ready()
+        return None, None
+    return get_ops().wgrad_bf16(dy2, x2, need_bias=bias is not None)
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x16 = x.to(torch.bfloat16)
-        # FlatParams.refresh_bf16() casts every parameter with ONE kernel per step; fall back to a
-        # per-call cast when the module is used outside the trainer
-        w16 = getattr(weight, "_basd_bf16", None)
-        if w16 is None:
-            w16 = weight.to(torch.bfloat16)
-        b16 = None
-        if bias is not None:
-            b16 = getattr(bias, "_basd_bf16", None)
-            if b16 is None:
-                b16 = bias.to(torch.bfloat16)
+        w16, b16 = _bf16_of(weight), _bf16_of(bias)
         ctx.save_for_backward(x16, w16)
         ctx.weight, ctx.bias = weight, bias
         ctx.x_dtype = x.dtype
@@ -47,24 +70,64 @@ class _LinearFn(torch.autograd.Function):
             ops = get_ops()
             if ops.gemm_supported(w16.shape[1], w16.shape[0]):
                 # dX = dY W as the same "NT" kernel on the transposed weight (<= 0.6 M elements: the copy is noise)
-                gx = ops.gemm_bf16(g16, w16.t().contiguous()).to(ctx.x_dtype)
+                gx = ops.gemm_bf16(g16, _bf16_transposed(weight, w16)).to(ctx.x_dtype)
             else:
                 gx = (g16 @ w16).to(ctx.x_dtype)
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
-            sink_w = getattr(weight, "_basd_grad", None)
-            sink_b = getattr(bias, "_basd_grad", None) if bias is not None else None
-            dy2, x2 = g16.reshape(-1, g16.shape[-1]), x16.reshape(-1, x16.shape[-1])
-            if sink_w is not None and (bias is None or sink_b is not None):
-                # accumulate straight into the flat fp32 gradient buffer: no temporary, no
-                # AccumulateGrad add kernel; tell the data-parallel reducer the slots are ready
-                get_ops().wgrad_bf16(dy2, x2, need_bias=bias is not None, out_w=sink_w, out_b=sink_b)
-                for p in (weight, bias):
-                    ready = getattr(p, "_basd_ready", None) if p is not None else None
-                    if ready is not None:
-                        ready()
-            else:
-                gw, gb = get_ops().wgrad_bf16(dy2, x2, need_bias=bias is not None)
+            gw, gb = _weight_grads(weight, bias, g16.reshape(-1, g16.shape[-1]), x16.reshape(-1, x16.shape[-1]))
         return gx, gw, gb
+
+
+class _MlpFn(torch.autograd.Function):
+    """fc1 -> GELU -> fc2 of a trained block (timm Mlp): the GELU rides in the epilogue of the fc1 GEMM (which also
+    stores the pre-activation) and its backward in the epilogue of fc2's input-gradient GEMM: two elementwise passes
+    over the [B T, hidden] activations less per block and direction."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ops = get_ops()
+        x16 = x.to(torch.bfloat16)
+        w1_16, w2_16 = _bf16_of(w1), _bf16_of(w2)
+        pre, act = ops.gemm_gelu_fwd(x16, w1_16, _bf16_of(b1))
+        y = ops.gemm_bf16(act, w2_16, _bf16_of(b2))
+        ctx.save_for_backward(x16, pre, act, w1_16, w2_16)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.x_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x16, pre, act, w1_16, w2_16 = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        ops = get_ops()
+        g16 = g.to(torch.bfloat16).contiguous()
+        hidden, d_in = w1_16.shape
+        dpre = ops.gemm_gelu_bwd(g16, _bf16_transposed(w2, w2_16), pre)     # (dY W2) * gelu'(pre)
+        gw2, gb2 = _weight_grads(w2, b2, g16.reshape(-1, g16.shape[-1]), act.reshape(-1, hidden))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.gemm_bf16(dpre, _bf16_transposed(w1, w1_16)).to(ctx.x_dtype)
+        gw1, gb1 = _weight_grads(w1, b1, dpre.reshape(-1, hidden), x16.reshape(-1, d_in))
+        return gx, gw1, gb1, gw2, gb2
+
+
+def fused_mlp_ok(x, fc1: "BasdLinear", fc2: "BasdLinear") -> bool:
+    """both layers trained, on device activations, every GEMM of forward and backward tiled by the own kernels"""
+    ops = get_ops()
+    return (ops.handles(x) and torch.is_grad_enabled() and x.dim() >= 2 and x.numel() // x.shape[-1] >= 64
+            and fc1.weight.requires_grad and fc2.weight.requires_grad
+            and fc1.bias is not None and fc2.bias is not None and fc1.bias.requires_grad and fc2.bias.requires_grad
+            and ops.gemm_supported(fc1.out_features, fc1.in_features)        # fc1 forward
+            and ops.gemm_supported(fc2.out_features, fc2.in_features)        # fc2 forward
+            and ops.gemm_supported(fc2.in_features, fc2.out_features)        # fc2 input gradient (+ GELU backward)
+            and ops.gemm_supported(fc1.in_features, fc1.out_features)        # fc1 input gradient
+            and ops.wgrad_supported(fc1.out_features, fc1.in_features)
+            and ops.wgrad_supported(fc2.out_features, fc2.in_features))
+
+
+def fused_mlp(x, fc1: "BasdLinear", fc2: "BasdLinear"):
+    with torch.autocast(device_type=x.device.type, enabled=False):
+        return _MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
 
 
 class BasdLinear(nn.Linear):

@@ -28,7 +28,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from ..losses._ops import get_ops
-from .linear import BasdLinear
+from .linear import BasdLinear, _LinearFn, fused_mlp, fused_mlp_ok
 
 
 class DropPath(nn.Module):
@@ -290,6 +290,8 @@ class Mlp(nn.Module):
     def forward(self, x):
         if self.fc1.fused_inference_ok(x):        # frozen block: exact-erf GELU in the epilogue of the fc1 GEMM
             return self.fc2(get_ops().gemm_bf16(x, self.fc1.weight, self.fc1.bias, gelu=True))
+        if fused_mlp_ok(x, self.fc1, self.fc2):   # trained block: GELU forward / backward inside the GEMM epilogues
+            return fused_mlp(x, self.fc1, self.fc2)
         return self.fc2(self.act(self.fc1(x)))
 
 
@@ -323,9 +325,8 @@ class Block(nn.Module):
 
     def forward(self, x, dp_masks=None):
         if self._fused_training(x):
-            m1, m2 = dp_masks if dp_masks is not None else (None, None)
-            sc1 = None if m1 is None else m1.reshape(-1).float()
-            sc2 = None if m2 is None else m2.reshape(-1).float()
+            # (bf16 mask, bf16 mask, fp32 per-sample scale, fp32 per-sample scale): the model draws all of them at once
+            m1, m2, sc1, sc2 = dp_masks if dp_masks is not None else (None, None, None, None)
             a = self.attn(self.norm1(x))
             x, z = _AddLayerNormFn.apply(a, x, sc1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
             m = self.mlp(z)
@@ -345,7 +346,7 @@ class Block(nn.Module):
             out, zn = nxt.fused_add(x, m)
             out._basd_prenorm = (nxt, zn)
             return out
-        m1, m2 = dp_masks if dp_masks is not None else (None, None)
+        m1, m2 = dp_masks[:2] if dp_masks is not None else (None, None)
         x = self.drop_path1.add_to(x, self.ls1(self.attn(self.norm1(x))), m1)
         return self.drop_path2.add_to(x, self.ls2(self.mlp(self.norm2(x))), m2)
 
@@ -363,8 +364,43 @@ class PatchEmbed(nn.Module):
         # naive bf16 convolution here (24 ms fwd + 31 ms wrw per call at B=256).
         b, c, h, w = x.shape
         p = self.patch_size
-        patches = x.reshape(b, c, h // p, p, w // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, c * p * p)
-        return F.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+        d, k = self.proj.weight.shape[0], c * p * p
+        unfolded = x.reshape(b, c, h // p, p, w // p, p).permute(0, 2, 4, 1, 3, 5)
+        ops = get_ops()
+        trained = torch.is_grad_enabled() and self.proj.weight.requires_grad
+        if ops.handles(x) and self._bf16_compute(x) and ops.gemm_supported(d, k) and (
+                not trained or ops.wgrad_supported(d, k)) and self.proj.bias is not None:
+            # own GEMM (forward) / split-M weight gradient; the unfold and the cast to bf16 are ONE copy kernel
+            patches = torch.empty(b, (h // p) * (w // p), k, dtype=torch.bfloat16, device=x.device)
+            patches.view(b, h // p, w // p, c, p, p).copy_(unfolded)
+            w2 = _matrix_view(self.proj.weight)
+            if trained:
+                with torch.autocast(device_type=x.device.type, enabled=False):
+                    return _LinearFn.apply(patches, w2, self.proj.bias)
+            if not torch.is_grad_enabled() and w2.dtype == torch.bfloat16 and self.proj.bias.dtype == torch.bfloat16:
+                return ops.gemm_bf16(patches, w2, self.proj.bias)
+            return F.linear(patches, w2.to(torch.bfloat16), self.proj.bias.to(torch.bfloat16))
+        return F.linear(unfolded.reshape(b, -1, k), self.proj.weight.reshape(d, -1), self.proj.bias)
+
+    def _bf16_compute(self, x) -> bool:
+        if self.proj.weight.dtype == torch.bfloat16:
+            return True                                      # frozen bf16 teacher
+        dev = x.device.type
+        return torch.is_autocast_enabled(dev) and torch.get_autocast_dtype(dev) == torch.bfloat16
+
+
+def _matrix_view(weight: torch.Tensor) -> torch.Tensor:
+    """[D, C, p, p] convolution weight as the [D, C p p] matrix of the GEMM; the bf16 image, the gradient slot in the
+    flat buffer and the data-parallel hook of the parameter (trainer attributes) follow the view"""
+    w2 = weight.view(weight.shape[0], -1)
+    for name in ("_basd_bf16", "_basd_grad"):
+        t = getattr(weight, name, None)
+        if t is not None:
+            setattr(w2, name, t.view(weight.shape[0], -1))
+    ready = getattr(weight, "_basd_ready", None)
+    if ready is not None:
+        w2._basd_ready = ready
+    return w2
 
 
 class VisionTransformer(nn.Module):
@@ -400,7 +436,7 @@ class VisionTransformer(nn.Module):
         x = x + self.pos_embed.to(x.dtype)
         masks = self._draw_drop_path_masks(x)
         for i, blk in enumerate(self.blocks):
-            dp = None if masks is None else (masks[2 * i], masks[2 * i + 1])
+            dp = None if masks is None else (masks[0][2 * i], masks[0][2 * i + 1], masks[1][2 * i], masks[1][2 * i + 1])
             if self.grad_checkpointing and self.training and torch.is_grad_enabled():
                 x = checkpoint(blk, x, dp, use_reentrant=False)
             else:
@@ -409,7 +445,8 @@ class VisionTransformer(nn.Module):
 
     def _draw_drop_path_masks(self, x):
         """All 2 * depth stochastic-depth masks of one forward from ONE bernoulli launch (timm draws one per
-        DropPath call: 3 tiny kernels x 24); [2 * depth, B, 1, 1], already divided by the keep probability."""
+        DropPath call: 3 tiny kernels x 24), already divided by the keep probability: ([2 * depth, B, 1, 1] in the
+        activation dtype, [2 * depth, B] fp32)."""
         if not self.training:
             return None
         ps = [p for blk in self.blocks for p in (blk.drop_path1.p, blk.drop_path2.p)]
@@ -419,8 +456,8 @@ class VisionTransformer(nn.Module):
         if keep is None or keep.device != x.device or keep.shape[0] != len(ps):
             keep = torch.tensor([1.0 - p for p in ps], device=x.device, dtype=torch.float32).view(-1, 1)
             self._dp_keep = keep
-        m = torch.bernoulli(keep.expand(-1, x.shape[0])) / keep
-        return m.to(x.dtype).view(len(ps), x.shape[0], 1, 1)
+        m = torch.bernoulli(keep.expand(-1, x.shape[0])) / keep          # fp32 [2 * depth, B]: the fused kernels' scales
+        return m.to(x.dtype).view(len(ps), x.shape[0], 1, 1), m
 
     def forward(self, x):
         x = self.forward_features(x)

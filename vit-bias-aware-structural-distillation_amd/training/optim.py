@@ -31,28 +31,43 @@ class FlatParams:
         self.data = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.data16 = None
+        self.data16_t, self._t_table = None, []
         for p, o in zip(self.params, offs):
             n = p.numel()
             self.data[o:o + n].copy_(p.data.reshape(-1).float())
             p.data = self.data[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
 
-    def enable_bf16_shadow(self, params=None) -> None:
+    def enable_bf16_shadow(self, params=None, transposed=None) -> None:
         """Keep a bf16 copy of the whole buffer (refreshed by ONE cast kernel per step) and expose, on
         each listed parameter, ``_basd_bf16`` (its bf16 view) and ``_basd_grad`` (its fp32 gradient
-        slot) for kernels that read the half-precision weight / accumulate gradients directly."""
+        slot) for kernels that read the half-precision weight / accumulate gradients directly.
+        ``transposed``: 2-D weights that also get ``_basd_bf16_t`` (bf16 W^T, the operand of the input-gradient
+        GEMM), all refreshed by one more launch."""
         self.data16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.data.device)
         chosen = None if params is None else {id(p) for p in params}
+        want_t = set() if transposed is None else {id(p) for p in transposed}
+        t_total = 0
         for p, o in zip(self.params, self.offsets):
             if chosen is None or id(p) in chosen:
                 n = p.numel()
                 p._basd_bf16 = self.data16[o:o + n].view(p.shape)
                 p._basd_grad = self.grad[o:o + n].view(p.shape)
+            if id(p) in want_t and p.dim() == 2:
+                self._t_table.append((o, t_total, p.shape[0], p.shape[1]))
+                t_total += (p.numel() + 63) // 64 * 64
+        if self._t_table:
+            self.data16_t = torch.empty(t_total, dtype=torch.bfloat16, device=self.data.device)
+            by_offset = {o: p for p, o in zip(self.params, self.offsets)}
+            for src, dst, rows, cols in self._t_table:
+                by_offset[src]._basd_bf16_t = self.data16_t[dst:dst + rows * cols].view(cols, rows)
         self.refresh_bf16()
 
     def refresh_bf16(self) -> None:
         if self.data16 is not None:
             self.data16.copy_(self.data)
+        if self.data16_t is not None:
+            get_ops().transpose_table(self.data, self.data16_t, self._t_table)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -68,10 +68,11 @@ class Trainer:
         self.optimizer = AdamWScheduleFree(self.flat, lr=config.training.learning_rate,
                                            weight_decay=config.training.weight_decay)
         from ..models.linear import BasdLinear
-        from ..models.vit import MixedLayerNorm
-        lin_params = [q for m in student_model.modules() if isinstance(m, (BasdLinear, MixedLayerNorm))
+        from ..models.vit import MixedLayerNorm, PatchEmbed
+        lin_params = [q for m in student_model.modules() if isinstance(m, (BasdLinear, MixedLayerNorm, PatchEmbed))
                       for q in m.parameters()]
-        self.flat.enable_bf16_shadow(lin_params)
+        lin_weights = [m.weight for m in student_model.modules() if isinstance(m, BasdLinear)]
+        self.flat.enable_bf16_shadow(lin_params, transposed=lin_weights)
         if config.basd.get("bucket_mb") is not None:          # optional key: all-reduce bucket size in MiB
             bucket_bytes = int(float(config.basd.bucket_mb) * (1 << 20))
         self.reducer = GradientReducer(self.flat, bucket_bytes=bucket_bytes)
@@ -245,8 +246,13 @@ class Trainer:
         """One optimisation step on a device-resident batch {"clean","augmented","label"}."""
         self._poll_status()
         clean, student_imgs, targets = batch["clean"], batch["augmented"], batch["label"]
+        graph_fits = self._graph is not None and clean.shape == self._g_clean.shape and \
+            student_imgs.shape == self._g_imgs.shape
         if self.use_mixup:
-            student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes)
+            # with a captured step the blend is written straight into the graph's static input buffers
+            student_imgs, mixed_targets = mixup_cutmix(student_imgs, targets, self.num_classes,
+                                                       out=self._g_imgs if graph_fits else None,
+                                                       out_targets=self._g_targets if graph_fits else None)
         else:
             mixed_targets = targets
         if self._graph is not None and (clean.shape != self._g_clean.shape or student_imgs.shape != self._g_imgs.shape):
@@ -264,10 +270,12 @@ class Trainer:
             return loss, logits
         if self._graph is not None:
             self._g_clean.copy_(clean)
-            self._g_imgs.copy_(student_imgs)
-            if mixed_targets.dim() == 1:
-                mixed_targets = torch.nn.functional.one_hot(mixed_targets, self.num_classes).float()
-            self._g_targets.copy_(mixed_targets)
+            if student_imgs is not self._g_imgs:
+                self._g_imgs.copy_(student_imgs)
+            if mixed_targets is not self._g_targets:
+                if mixed_targets.dim() == 1:
+                    mixed_targets = torch.nn.functional.one_hot(mixed_targets, self.num_classes).float()
+                self._g_targets.copy_(mixed_targets)
             self._graph.replay()
             loss, logits = self._g_loss, self._g_logits
             self.reducer.reduce_all()
