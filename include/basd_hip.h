@@ -219,6 +219,15 @@ int basd_gemm_bf16_gelu_bwd(const void* dy, const void* wt, const void* pre, voi
 int basd_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, float* dw, float* db,
                     void* stream);
 
+/* The same with a caller-provided workspace: shapes with N % 192 == 0, K % 192 == 0, M >= 4096 (every ViT student
+ * width) run as 192 x 192 tiles whose per-slab partial sums go through the workspace and a reduction launch instead of
+ * 256-way fp32 atomics (which execute at the memory side: 31 - 48 us per launch).  basd_wgrad_workspace_bytes returns
+ * the bytes this shape needs (0: no workspace used; <= 37.75 MB); the workspace is scratch, 16-byte aligned, and may
+ * be shared by all launches of a stream. */
+int64_t basd_wgrad_workspace_bytes(int64_t M, int N, int K);
+int basd_wgrad_bf16_ws(const void* dy, const void* x, int64_t M, int N, int K, float* dw, float* db,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 /* LayerNorm of the ViT blocks (timm nn.LayerNorm, eps 1e-6): bf16 activations in/out, fp32 gamma/beta,
  * fp32 statistics.  fwd saves mean / rstd [rows]; bwd writes dx and ACCUMULATES dgamma / dbeta
  * (fp32 atomics; pass NULL for a frozen layer).  D % 8 == 0, D <= 2048. */

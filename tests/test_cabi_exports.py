@@ -13,7 +13,7 @@ def test_header_and_library_agree():
         native.build()
     lib = ctypes.CDLL(native.LIB_PATH)
     header = open(os.path.join(ROOT, "include", "basd_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(basd_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(basd_\w+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in basd_hip.h but not exported"
@@ -31,7 +31,7 @@ def test_ctypes_signatures_match_the_header():
     header = open(os.path.join(ROOT, "include", "basd_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     seen = 0
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(basd_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(basd_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
         want = []
         for a in ([] if args in ("void", "") else args.split(",")):

@@ -455,7 +455,9 @@ def test_fused_mlp_matches_the_unfused_layers():
         assert float((a - b).norm() / b.norm()) < 6e-3, float((a - b).norm() / b.norm())
 
 
-@pytest.mark.parametrize("M,N,K", [(50432, 576, 192), (1000, 192, 768), (333, 64, 64), (4096, 768, 192), (777, 128, 128)])
+@pytest.mark.parametrize("M,N,K", [(50432, 576, 192), (1000, 192, 768), (333, 64, 64), (4096, 768, 192), (777, 128, 128),
+                                   (50432, 192, 768), (50432, 192, 192), (50433, 768, 192), (4100, 384, 1536),
+                                   (12345, 192, 384)])
 def test_wgrad_bf16(nat, M, N, K):
     g = torch.Generator().manual_seed(M + N)
     dy = (torch.randn(M, N, generator=g) * 0.1).bfloat16()

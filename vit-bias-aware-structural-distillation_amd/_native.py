@@ -21,7 +21,7 @@ JACOBI_LDS_BYTES = 163840
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_angle_weights", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
-    "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_gemm_bf16",
+    "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
     "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
 )
@@ -45,6 +45,8 @@ _SIGNATURES = {
     "basd_transpose_bf16_table": (_P, _P, _P, _I, _P),
     "basd_bgemm_f64": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P),
     "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
+    "basd_wgrad_workspace_bytes": (_I64, _I, _I),
+    "basd_wgrad_bf16_ws": (_P, _P, _I64, _I, _I, _P, _P, _P, _I64, _P),
     "basd_gemm_bf16": (_P, _P, _P, _P, _I64, _I, _I, _I, _P),
     "basd_gemm_bf16_gelu_fwd": (_P, _P, _P, _P, _P, _I64, _I, _I, _P),
     "basd_gemm_bf16_gelu_bwd": (_P, _P, _P, _P, _I64, _I, _I, _P),
@@ -103,7 +105,8 @@ def lib() -> ctypes.CDLL:
                 raise BasdNativeError(f"{LIB_PATH} does not export {name}")
             fn = getattr(L, name)
             fn.argtypes = list(_SIGNATURES[name])      # explicit: no default int conversion of 64-bit sizes / pointers
-            fn.restype = ctypes.c_char_p if name == "basd_last_error" else ctypes.c_int
+            fn.restype = (ctypes.c_char_p if name == "basd_last_error" else
+                          ctypes.c_int64 if name.endswith("_workspace_bytes") else ctypes.c_int)
         _lib = L
     return _lib
 
@@ -587,9 +590,30 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True, out_w:
     dw = out_w if out_w is not None else torch.zeros(n, k, dtype=torch.float32, device=dy.device)
     db = out_b if out_b is not None else (torch.zeros(n, dtype=torch.float32, device=dy.device) if need_bias else None)
     assert dw.is_contiguous() and dw.dtype == torch.float32 and dw.shape == (n, k)
-    _check(lib().basd_wgrad_bf16(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _stream()),
-           "basd_wgrad_bf16")
+    need = int(lib().basd_wgrad_workspace_bytes(ctypes.c_int64(m), n, k))
+    if need > 0:
+        ws = _wgrad_workspace(dy.device, need)
+        _check(lib().basd_wgrad_bf16_ws(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _ptr(ws),
+                                        ctypes.c_int64(ws.numel() * 4), _stream()), "basd_wgrad_bf16_ws")
+    else:
+        _check(lib().basd_wgrad_bf16(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _stream()),
+               "basd_wgrad_bf16")
     return dw, db
+
+
+_WGRAD_WS: dict = {}
+
+
+def _wgrad_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """scratch for the partial tiles of basd_wgrad_bf16_ws, one per device (<= 37.75 MB): the weight-gradient launches
+    of a backward pass run one after the other on one stream and share it; it is allocated by the first call, i.e. by
+    the warm-up steps before any graph capture"""
+    key = device.index
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, 256 * 192 * 192 * 4) // 4, dtype=torch.float32, device=device)
+        _WGRAD_WS[key] = ws
+    return ws
 
 
 def cls_importance_supported(t: int, hd: int) -> bool:
