@@ -278,6 +278,30 @@ int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int hd, float 
 int basd_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int T, int H,
                             int hd, float scale, void* dqkv, void* stream);
 
+/* Forward of the attention-weighted Procrustes term between basd_procrustes_prep and the loss value, as one chain of
+ * launches on a caller-provided workspace (src/losses/relational.py:47-48: cross = s_w^T t_w, its nuclear norm, and
+ * U V^T for the backward; cross is never formed).  s_w [batch, n, d_s], t_w [batch, n, d_t] fp32 (prep outputs);
+ * tol: relative stop of the pivoted Cholesky factorisations (1e-13).  Outputs (fp32):
+ *   nuc [batch]: nuclear norm of cross;   a_t [batch, n, n]:  s_w (U V^T) = a_t t_w;
+ *   fac_s: n > d_s  ("feature side"): [batch, n, d_s] = t_w (U V^T)^T;
+ *          n <= d_s ("token side"):   [batch, n, n]   = a_s with t_w (U V^T)^T = a_s s_w.
+ * status: device health word (BASD_STATUS_* OR-ed in by the Jacobi solve; nullable).  min(n, d_s) <= 256.
+ * basd_procrustes_workspace_bytes gives the workspace size (256-byte aligned scratch; 5 or 10 fp64 [batch, n, n]
+ * matrices plus the fp32 Jacobi image). */
+int64_t basd_procrustes_workspace_bytes(int batch, int n, int d_s, int d_t);
+int basd_procrustes_fwd(const float* s_w, const float* t_w, int batch, int n, int d_s, int d_t, double tol,
+                        float* nuc, float* fac_s, float* a_t, int32_t* status, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
+/* Cross-entropy with label smoothing on soft targets [B, C] (MixUp / CutMix) or class indices [B] (exactly one of the
+ * two non-NULL), its gradient, and the UW-SO combination with the Procrustes term (src/losses/combined.py:57,78-85;
+ * nn.CrossEntropyLoss(label_smoothing) of trainer.py:47):  ce = mean_b -sum_c t'_bc log_softmax(z_b)_c,
+ * w_ce = (1/ce) / (1/ce + 1/geo), w_geo = 1 - w_ce (detached, clamped at eps), total = w_ce ce + w_geo geo.
+ * geo: DEVICE scalar (NULL: plain CE, w_ce = 1).  Outputs: dlogits [B, C] = d total / d logits, out4 = {total, ce,
+ * w_ce, w_geo} (device; d total / d geo = w_geo); row_loss [B] is scratch.  All fp32. */
+int basd_ce_uwso(const float* logits, const float* soft_targets, const int64_t* labels, int B, int C,
+                 float smoothing, const float* geo, float* row_loss, float* dlogits, float* out4, void* stream);
+
 /* Fused Schedule-Free AdamW step (schedulefree 1.4.1 AdamWScheduleFree, train mode;
  * reference src/training/trainer.py:54-58,158-159) over one flat fp32 buffer of n params:
  *   v = b2 v + (1-b2) g^2 ; gn = g / (sqrt(v / bias_correction2) + eps) + wd * y

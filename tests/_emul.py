@@ -273,6 +273,32 @@ def gemm_bf16(x, w, bias=None, gelu=False):
     return y.to(torch.bfloat16)
 
 
+def procrustes_fwd(s_w, t_w, tol=1e-13):
+    import sys
+    from tests._procrustes_chain import procrustes_fwd_chain
+    return procrustes_fwd_chain(sys.modules[__name__], s_w, t_w, tol)
+
+
+def ce_uwso(logits, targets, smoothing, geo):
+    z = logits.detach().double()
+    b, c = z.shape
+    t = targets.double() if targets.dim() == 2 else torch.nn.functional.one_hot(targets, c).double()
+    t = (1.0 - smoothing) * t + smoothing / c
+    logp = torch.log_softmax(z, dim=-1)
+    ce = -(t * logp).sum(-1).mean()
+    eps = torch.finfo(torch.float32).eps
+    if geo is None:
+        w_ce, w_geo, g = 1.0, 0.0, 0.0
+    else:
+        g = geo.detach().double().reshape(())
+        ic, ig = 1.0 / ce.clamp_min(eps), 1.0 / g.clamp_min(eps)
+        w_ce, w_geo = ic / (ic + ig), ig / (ic + ig)
+    dl = (logp.exp() * t.sum(-1, keepdim=True) - t) * (w_ce / b)
+    out4 = torch.stack([torch.as_tensor(w_ce * ce + w_geo * g), ce, torch.as_tensor(w_ce).double(),
+                        torch.as_tensor(w_geo).double()]).float()
+    return out4, dl.float()
+
+
 def transpose_table(master, out, table):
     for src, dst, rows, cols in table:
         out[dst:dst + rows * cols].view(cols, rows).copy_(master[src:src + rows * cols].view(rows, cols).t())

@@ -415,6 +415,81 @@ def test_gemm_bf16_gelu_training_pair(nat, M, hidden, d):
     assert float((err / (ref.abs() + 1e-2 * float(ref.abs().max()))).max()) < 1.2e-2
 
 
+@pytest.mark.parametrize("B,C,soft,smoothing,with_geo", [(256, 1000, True, 0.1, True), (256, 1000, False, 0.1, True),
+                                                          (7, 10, True, 0.0, True), (33, 100, False, 0.05, False)])
+def test_ce_uwso_matches_torch(nat, B, C, soft, smoothing, with_geo):
+    """basd_ce_uwso: CE(label smoothing; soft or hard targets) + UW-SO weights + d total / d logits in two launches,
+    against nn.CrossEntropyLoss and the reference's weighting arithmetic through autograd"""
+    g = torch.Generator().manual_seed(B + C)
+    logits = (torch.randn(B, C, generator=g) * 3).cuda()
+    if soft:
+        t = torch.rand(B, C, generator=g)
+        targets = (t / t.sum(-1, keepdim=True)).cuda()
+    else:
+        targets = torch.randint(C, (B,), generator=g).cuda()
+    geo = torch.tensor(3.7, device="cuda") if with_geo else None
+    out4, dl = nat.ce_uwso(logits, targets, smoothing, geo)
+    z = logits.double().requires_grad_(True)
+    ce = torch.nn.CrossEntropyLoss(label_smoothing=smoothing)(z, targets.double() if soft else targets)
+    if with_geo:
+        inv = torch.stack([1.0 / ce.detach(), 1.0 / geo.double()])
+        w = inv / inv.sum()
+        total = w[0] * ce + w[1] * geo.double()
+    else:
+        w = torch.tensor([1.0, 0.0], device="cuda", dtype=torch.float64)
+        total = ce
+    total.backward()
+    want4 = torch.stack([total.detach(), ce.detach(), w[0], w[1]])
+    torch.testing.assert_close(out4.double(), want4, rtol=3e-6, atol=1e-7)
+    assert float((dl.double() - z.grad).norm() / z.grad.norm()) < 3e-6
+
+
+@pytest.mark.parametrize("batch,n,d_s,d_t", [(6, 196, 192, 768), (5, 64, 192, 384), (4, 196, 384, 1024), (3, 40, 24, 56)])
+def test_procrustes_fwd_composite_equals_the_kernel_chain(nat, batch, n, d_s, d_t):
+    """basd_procrustes_fwd (one C call on a workspace) against the same chain built from the individually exported
+    entries (tests/_procrustes_chain.py): feature side (n > d_s) and token side (n <= d_s); then against torch's SVD"""
+    from tests._procrustes_chain import procrustes_fwd_chain
+    g = torch.Generator().manual_seed(batch * n + d_s)
+    s_w = (torch.randn(batch, n, d_s, generator=g) / n ** 0.5).cuda()
+    t_w = (torch.randn(batch, n, d_t, generator=g) / n ** 0.5).cuda()
+    s_w -= s_w.mean(1, keepdim=True)
+    t_w -= t_w.mean(1, keepdim=True)
+    nuc, fac_s, a_t = nat.procrustes_fwd(s_w, t_w, 1e-13)
+    nat.check_status()
+    nuc2, fac2, at2 = procrustes_fwd_chain(nat, s_w, t_w, 1e-13)
+    torch.testing.assert_close(nuc, nuc2, rtol=1e-6, atol=0)
+    torch.testing.assert_close(fac_s, fac2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a_t, at2, rtol=1e-5, atol=1e-6)
+    cross = s_w.double().transpose(1, 2) @ t_w.double()
+    u, sv, vh = torch.linalg.svd(cross, full_matrices=False)
+    torch.testing.assert_close(nuc.double(), sv.sum(-1), rtol=2e-6, atol=0)
+    gpol = u @ vh                                                   # [d_s, d_t]; full rank here (n - 1 >= d_s) or not
+    want_pt = s_w.double() @ gpol                                   # s_w G = a_t t_w
+    got_pt = a_t.double() @ t_w.double()
+    want_ps = t_w.double() @ gpol.transpose(1, 2)                   # t_w G^T
+    got_ps = fac_s.double() if n > d_s else fac_s.double() @ s_w.double()
+    if n - 1 >= d_s:                                                # G unique
+        assert float((got_pt - want_pt).norm() / want_pt.norm()) < 2e-5
+        assert float((got_ps - want_ps).norm() / want_ps.norm()) < 2e-5
+    else:                                                           # the null-space part of G cancels in these products
+        assert float((got_pt - want_pt).norm() / want_pt.norm()) < 2e-5
+        assert float((got_ps - want_ps).norm() / want_ps.norm()) < 2e-5
+
+
+def test_procrustes_fwd_rejects_a_short_workspace(nat):
+    import ctypes
+    lib = nat.lib()
+    need = lib.basd_procrustes_workspace_bytes(4, 196, 192, 768)
+    assert need > 4 * 5 * 196 * 196 * 8
+    s_w = torch.zeros(4, 196, 192, device="cuda")
+    t_w = torch.zeros(4, 196, 768, device="cuda")
+    out = torch.zeros(4, 196, 196, device="cuda")
+    ws = torch.empty(need // 2, dtype=torch.uint8, device="cuda")
+    rc = lib.basd_procrustes_fwd(s_w.data_ptr(), t_w.data_ptr(), 4, 196, 192, 768, ctypes.c_double(1e-13), out.data_ptr(),
+                                 out.data_ptr(), out.data_ptr(), None, ws.data_ptr(), ctypes.c_int64(ws.numel()), None)
+    assert rc == 3 and b"workspace" in lib.basd_last_error()          # BASD_ERR_WORKSPACE
+
+
 def test_transpose_table_all_weights_in_one_launch(nat):
     """bf16 W^T images of many matrices of the flat fp32 master buffer (ragged shapes, > 64 entries = two launches)"""
     g = torch.Generator().manual_seed(5)

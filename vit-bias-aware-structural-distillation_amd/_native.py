@@ -20,7 +20,8 @@ JACOBI_LDS_BYTES = 163840
 
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
-    "basd_mp_rank", "basd_angle_weights", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
+    "basd_mp_rank", "basd_angle_weights", "basd_ce_uwso",
+    "basd_procrustes_workspace_bytes", "basd_procrustes_fwd", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
     "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
@@ -42,6 +43,9 @@ _SIGNATURES = {
     "basd_mix_tokens": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
     "basd_procrustes_prep": (_P, _I, _I64, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P),
     "basd_mix_grad_dots": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
+    "basd_procrustes_workspace_bytes": (_I, _I, _I, _I),
+    "basd_procrustes_fwd": (_P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _I64, _P),
+    "basd_ce_uwso": (_P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P),
     "basd_transpose_bf16_table": (_P, _P, _P, _I, _P),
     "basd_bgemm_f64": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P),
     "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
@@ -468,6 +472,57 @@ def lerp_(y, z, w: float) -> None:
     _need_cuda(y, z)
     assert y.dtype == torch.float32 and z.dtype == torch.float32 and y.numel() == z.numel()
     _check(lib().basd_lerp(_ptr(y), _ptr(z), ctypes.c_int64(y.numel()), ctypes.c_float(w), _stream()), "basd_lerp")
+
+
+_PROCRUSTES_WS: dict = {}
+
+
+def procrustes_fwd(s_w: torch.Tensor, t_w: torch.Tensor, tol: float = 1e-13):
+    """s_w [batch, n, d_s], t_w [batch, n, d_t] fp32 (weighted, centred tokens from ``procrustes_prep``) ->
+    (nuc [batch], fac_s, a_t [batch, n, n]) fp32; fac_s = t_w G^T [batch, n, d_s] if n > d_s else a_s [batch, n, n]
+    (see basd_procrustes_fwd).  One C call; the scratch (per device, grown on demand, shared by the calls of a stream)
+    comes from torch's allocator outside any graph capture."""
+    _need_cuda(s_w, t_w)
+    assert s_w.dtype == torch.float32 and t_w.dtype == torch.float32 and s_w.shape[:2] == t_w.shape[:2]
+    s_w, t_w = s_w.contiguous(), t_w.contiguous()
+    batch, n, d_s = s_w.shape
+    d_t = t_w.shape[2]
+    need = int(lib().basd_procrustes_workspace_bytes(batch, n, d_s, d_t))
+    ws = _PROCRUSTES_WS.get(s_w.device.index)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=s_w.device)
+        _PROCRUSTES_WS[s_w.device.index] = ws
+    nuc = torch.empty(batch, dtype=torch.float32, device=s_w.device)
+    fac_s = torch.empty(batch, n, d_s if n > d_s else n, dtype=torch.float32, device=s_w.device)
+    a_t = torch.empty(batch, n, n, dtype=torch.float32, device=s_w.device)
+    _check(lib().basd_procrustes_fwd(_ptr(s_w), _ptr(t_w), batch, n, d_s, d_t, ctypes.c_double(tol), _ptr(nuc),
+                                     _ptr(fac_s), _ptr(a_t), _ptr(status_word(s_w.device)), _ptr(ws),
+                                     ctypes.c_int64(ws.numel()), _stream()), "basd_procrustes_fwd")
+    return nuc, fac_s, a_t
+
+
+def ce_uwso(logits: torch.Tensor, targets: torch.Tensor, smoothing: float, geo: torch.Tensor | None):
+    """logits [B, C] fp32; targets [B, C] float (soft) or [B] int64; geo: 0-d fp32 device tensor | None ->
+    (out4 = [total, ce, w_ce, w_geo] fp32 device, dlogits [B, C] = d total / d logits)."""
+    _need_cuda(logits, targets, geo)
+    assert logits.dtype == torch.float32 and logits.dim() == 2
+    logits = logits.contiguous()
+    b, c = logits.shape
+    soft = labels = None
+    if targets.dim() == 2:
+        assert targets.shape == (b, c)
+        soft = targets.float().contiguous()
+    else:
+        assert targets.shape == (b,)
+        labels = targets.to(torch.int64).contiguous()
+    if geo is not None:
+        geo = geo.detach().float().reshape(1).contiguous()
+    row = torch.empty(b, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits)
+    out4 = torch.empty(4, dtype=torch.float32, device=logits.device)
+    _check(lib().basd_ce_uwso(_ptr(logits), _ptr(soft), _ptr(labels), b, c, ctypes.c_float(smoothing), _ptr(geo), _ptr(row),
+                              _ptr(dl), _ptr(out4), _stream()), "basd_ce_uwso")
+    return out4, dl
 
 
 def transpose_table(master: torch.Tensor, out: torch.Tensor, table) -> None:

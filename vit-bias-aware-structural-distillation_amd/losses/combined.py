@@ -28,6 +28,23 @@ def _align_token_count(tokens: torch.Tensor, target_n: int) -> torch.Tensor:
     return torch.matmul(r, tokens)
 
 
+class _CeUwsoFn(torch.autograd.Function):
+    """total = w_ce CE(logits, targets) + w_geo geo with the detached UW-SO weights, one fused forward (which already
+    holds d total / d logits) instead of ~25 pointwise / reduction launches; returns (total, ce.detach())."""
+
+    @staticmethod
+    def forward(ctx, logits, geo, targets, smoothing):
+        out4, dl = BF.get_ops().ce_uwso(logits, targets, smoothing, geo)
+        ctx.save_for_backward(dl, out4)
+        ctx.mark_non_differentiable(out4)
+        return out4[0], out4
+
+    @staticmethod
+    def backward(ctx, g, _):
+        dl, out4 = ctx.saved_tensors
+        return dl * g, out4[3] * g, None, None
+
+
 class BASDLoss(nn.Module):
     def __init__(self, base_criterion: nn.Module, student_dim: int, teacher_dim: int,
                  student_depth: int, num_student_tokens: int, *, config, teacher_has_cls_token: bool):
@@ -44,8 +61,18 @@ class BASDLoss(nn.Module):
             num_extraction_points=len(self.token_layers), student_dim=student_dim, teacher_dim=teacher_dim)
         self.last_terms: dict[str, torch.Tensor] = {}
 
+    def _fused_ce(self, student_output, targets) -> bool:
+        """nn.CrossEntropyLoss(label_smoothing) in its default form on device logits: CE, its gradient and the UW-SO
+        combination run as one C entry (basd_ce_uwso); any other criterion takes the torch path"""
+        c = self.base_criterion
+        return (type(c) is nn.CrossEntropyLoss and c.weight is None and c.reduction == "mean"
+                and student_output.dim() == 2 and student_output.dtype == torch.float32
+                and BF.get_ops().handles(student_output)
+                and (targets.dim() == 2 or (targets.dim() == 1 and c.ignore_index < 0)))
+
     def forward(self, student_output, targets, student_intermediates, all_teacher_tokens, all_teacher_attns):
-        ce_loss = self.base_criterion(student_output, targets)
+        fused_ce = self._fused_ce(student_output, targets)
+        ce_loss = None if fused_ce else self.base_criterion(student_output, targets)
 
         sel = self.layer_selector
         weights, teacher_indices = sel.mixing_weights(student_intermediates, all_teacher_tokens, self.token_layers)
@@ -62,6 +89,10 @@ class BASDLoss(nn.Module):
             students.append(s)
         geo_each = BF.procrustes_all(students, mixed, mixed_imp).mean(dim=1)      # [E]
         geo_loss = geo_each.mean()
+        if fused_ce:
+            total, out4 = _CeUwsoFn.apply(student_output, geo_loss.float(), targets, float(self.base_criterion.label_smoothing))
+            self.last_terms = {"ce": out4[1], "geo": geo_each.detach()}
+            return total
 
         # UW-SO (reference combined.py:78-85): w_i = (1/L_i) / sum_j (1/L_j), detached
         eps = torch.finfo(ce_loss.dtype).eps
