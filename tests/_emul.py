@@ -275,7 +275,7 @@ def gemm_bf16(x, w, bias=None, gelu=False):
 
 def procrustes_fwd(s_w, t_w, tol=1e-13):
     import sys
-    from tests._procrustes_chain import procrustes_fwd_chain
+    from basd_amd.losses.procrustes_chain import procrustes_fwd_chain
     return procrustes_fwd_chain(sys.modules[__name__], s_w, t_w, tol)
 
 

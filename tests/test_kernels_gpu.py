@@ -447,8 +447,8 @@ def test_ce_uwso_matches_torch(nat, B, C, soft, smoothing, with_geo):
 @pytest.mark.parametrize("batch,n,d_s,d_t", [(6, 196, 192, 768), (5, 64, 192, 384), (4, 196, 384, 1024), (3, 40, 24, 56)])
 def test_procrustes_fwd_composite_equals_the_kernel_chain(nat, batch, n, d_s, d_t):
     """basd_procrustes_fwd (one C call on a workspace) against the same chain built from the individually exported
-    entries (tests/_procrustes_chain.py): feature side (n > d_s) and token side (n <= d_s); then against torch's SVD"""
-    from tests._procrustes_chain import procrustes_fwd_chain
+    entries (losses/procrustes_chain.py): feature side (n > d_s) and token side (n <= d_s); then against torch's SVD"""
+    from basd_amd.losses.procrustes_chain import procrustes_fwd_chain
     g = torch.Generator().manual_seed(batch * n + d_s)
     s_w = (torch.randn(batch, n, d_s, generator=g) / n ** 0.5).cuda()
     t_w = (torch.randn(batch, n, d_t, generator=g) / n ** 0.5).cuda()

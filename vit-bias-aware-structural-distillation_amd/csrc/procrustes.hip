@@ -20,10 +20,24 @@ __global__ __launch_bounds__(256) void polar_unit_rows_kernel(const float* __res
                                                               float* __restrict__ nuc) {
   const int b = blockIdx.x;
   const float* sg = sigma + (size_t)b * r;
-  for (int idx = threadIdx.x; idx < r * r; idx += 256) {
-    const int i = idx / r, c = idx - i * r;
-    const float s = sg[i];
-    u[((size_t)b * r + i) * r + c] = s > 0.f ? w0[((size_t)b * r + i) * ld + c] / fmaxf(s, 1e-30f) : 0.f;
+  if ((r & 3) == 0) {                                 // 16 bytes per lane (ld is a multiple of 4)
+    const int r4 = r >> 2;
+    for (int idx = threadIdx.x; idx < r * r4; idx += 256) {
+      const int i = idx / r4, c4 = idx - i * r4;
+      const float s = sg[i];
+      float4 v = *reinterpret_cast<const float4*>(w0 + ((size_t)b * r + i) * ld + 4 * c4);
+      v.x = s > 0.f ? v.x / fmaxf(s, 1e-30f) : 0.f;
+      v.y = s > 0.f ? v.y / fmaxf(s, 1e-30f) : 0.f;
+      v.z = s > 0.f ? v.z / fmaxf(s, 1e-30f) : 0.f;
+      v.w = s > 0.f ? v.w / fmaxf(s, 1e-30f) : 0.f;
+      *reinterpret_cast<float4*>(u + ((size_t)b * r + i) * r + 4 * c4) = v;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < r * r; idx += 256) {
+      const int i = idx / r, c = idx - i * r;
+      const float s = sg[i];
+      u[((size_t)b * r + i) * r + c] = s > 0.f ? w0[((size_t)b * r + i) * ld + c] / fmaxf(s, 1e-30f) : 0.f;
+    }
   }
   if (nuc != nullptr) {
     __shared__ float red[4];

@@ -1,7 +1,8 @@
-"""The forward of the Procrustes term as a chain of the individual kernel entries (pivoted Cholesky, Jacobi, triangular
-inverse, fp64 batched GEMMs) -- what ``basd_procrustes_fwd`` does inside the library.  Test infrastructure: the CPU
-emulation of that entry (``_emul.procrustes_fwd``) and the reference the GPU test compares the composite entry with
-(``ops`` = the provider whose kernels are used)."""
+"""The forward of the Procrustes term launched entry by entry (pivoted Cholesky, Jacobi, triangular inverse, fp64
+batched GEMMs): the SAME kernels, in the same order, that ``basd_procrustes_fwd`` chains inside the library.  The
+training path calls the composite entry; this form exists so that ``bench.py`` can put device events around the
+individual launches in its instrumented eager steps (nothing can be timed inside one C call), and as the reference the
+tests compare the composite entry with (``ops`` = the provider whose kernels are used)."""
 import torch
 
 
