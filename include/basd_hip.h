@@ -24,6 +24,12 @@
  *   basd_procrustes_prep   src/losses/relational.py:29-46, src/losses/combined.py:9-14
  *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
  *   basd_gemm_bf16         timm nn.Linear (+ nn.GELU) forward of the ViT blocks, teacher.py:212 / trainer.py:33
+ *   basd_gemm_bf16_gelu_fwd, basd_gemm_bf16_gelu_bwd
+ *                          timm Mlp (fc1 -> nn.GELU -> fc2) of the TRAINED student: forward and autograd (trainer.py:33,157)
+ *   basd_transpose_bf16_table
+ *                          the W^T operands autograd's nn.Linear backward forms per call (trainer.py:157)
+ *   basd_procrustes_fwd    src/losses/relational.py:47-48 (cross-covariance, nuclear norm, U V^T) as one call
+ *   basd_ce_uwso           nn.CrossEntropyLoss(label_smoothing) (trainer.py:47) + UW-SO (src/losses/combined.py:57,78-85)
  *   basd_wgrad_bf16        autograd of the student's timm nn.Linear layers (trainer.py:157)
  *   basd_sf_adamw_step     schedulefree.AdamWScheduleFree.step  src/training/trainer.py:54-58,158
  *   basd_bgemm_f64, basd_trinv_f64
