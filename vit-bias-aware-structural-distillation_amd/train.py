@@ -25,19 +25,29 @@ from .training.trainer import Trainer
 
 
 def _apply_fan_in_init(model: nn.Module) -> None:
-    for m in model.modules():
-        if isinstance(m, nn.Linear):
-            nn.init.trunc_normal_(m.weight, std=(2.0 / m.weight.shape[1]) ** 0.5)
-            if m.bias is not None:
-                nn.init.zeros_(m.bias)
-        elif isinstance(m, nn.LayerNorm):
-            nn.init.ones_(m.weight)
-            nn.init.zeros_(m.bias)
-        elif isinstance(m, nn.Conv2d):
-            fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
-            nn.init.normal_(m.weight, std=(2.0 / fan_out) ** 0.5)
-            if m.bias is not None:
-                nn.init.zeros_(m.bias)
+    """The reference's student initialisation rule (src/train.py:19-32), stated as a table: He-style standard deviations
+    sqrt(2 / fan) -- fan-in, truncated normal, for Linear; fan-out (k_h k_w C_out / groups), normal, for Conv2d --
+    LayerNorm at (1, 0) and every bias at 0.  Modules are visited in ``model.modules()`` order, so a seeded run draws
+    the same random numbers as the reference's."""
+    def he_std(fan: int) -> float:
+        return math.sqrt(2.0 / fan)
+
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, nn.LayerNorm):
+                if mod.elementwise_affine:
+                    mod.weight.fill_(1.0)
+                    mod.bias.zero_()
+                continue
+            if isinstance(mod, nn.Linear):
+                nn.init.trunc_normal_(mod.weight, std=he_std(mod.in_features))
+            elif isinstance(mod, nn.Conv2d):
+                k_h, k_w = mod.kernel_size
+                nn.init.normal_(mod.weight, std=he_std(k_h * k_w * mod.out_channels // mod.groups))
+            else:
+                continue
+            if mod.bias is not None:
+                mod.bias.zero_()
 
 
 def _create_student(model_name: str, *, num_classes: int, drop_path_rate: float, img_size: int,
@@ -53,6 +63,8 @@ def _create_student(model_name: str, *, num_classes: int, drop_path_rate: float,
 
 
 def _derive_from_teacher(teacher: TeacherModel, intrinsic_dim: int) -> dict:
+    """student width = the teacher's intrinsic dimension rounded up to whole teacher heads, capped at the teacher width;
+    depth / MLP ratio / head size follow the teacher (the rule of reference src/train.py:57-66)"""
     head_dim = teacher.embed_dim // teacher.heads_per_layer[0]
     d_s = min(math.ceil(intrinsic_dim / head_dim) * head_dim, teacher.embed_dim)
     return {"embed_dim": d_s, "depth": teacher.depth, "num_heads": d_s // head_dim, "mlp_ratio": teacher.mlp_ratio}
