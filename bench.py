@@ -149,8 +149,12 @@ def main():
     t_start = time.perf_counter()
     trainer, info = build(cfg, device=dev)
     progress(f"built {args.config}: {student_preset} / {teacher_preset}, {args.batch} images per GPU")
-    loader = SyntheticLoader(args.batch, cfg.model.vit.img_size, cfg.model.num_classes, 1, dev, seed=1234 + rank)
-    batch = next(iter(loader))
+    # four different synthetic batches, cycled through the warm-up and timed steps: no step sees the data of the
+    # previous one (nothing could be reused across steps, and the data-dependent Jacobi sweep counts vary); the
+    # instrumented probe steps use the first
+    batches = [next(iter(SyntheticLoader(args.batch, cfg.model.vit.img_size, cfg.model.num_classes, 1, dev,
+                                         seed=1234 + rank + 1000 * i))) for i in range(4)]
+    batch = batches[0]
     trainer.optimizer.train()
     trainer.model.train()
 
@@ -185,7 +189,7 @@ def main():
         graphed = trainer.enable_graph(batch)
         progress(f"hipGraph capture: {'ok' if graphed else 'failed: ' + str(trainer.graph_error)}")
     for i in range(args.warmup):
-        loss, _ = trainer.train_step(batch)
+        loss, _ = trainer.train_step(batches[i % len(batches)])
     torch.cuda.synchronize()
     progress(f"{args.warmup} warm-up steps done; timing {args.steps} steps")
 
@@ -200,9 +204,9 @@ def main():
     timer.active = False
     t0 = time.perf_counter()
     host_s = 0.0
-    for _ in range(args.steps):
+    for i in range(args.steps):
         th = time.perf_counter()
-        loss, _ = trainer.train_step(batch)
+        loss, _ = trainer.train_step(batches[(args.warmup + i) % len(batches)])
         host_s += time.perf_counter() - th      # time to ENQUEUE a step (no device sync inside)
     barrier()
     elapsed = time.perf_counter() - t0

@@ -31,6 +31,22 @@ constexpr int GBK = 64;    // K step
 
 __device__ __forceinline__ int gemm_swz(int byte) { return byte ^ (((byte >> 9) & 1) << 5); }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (lin & 7), each with its own 4 MB L2; XCD x owns
+// the 256-row blocks mb = x (mod 8).  Inside an XCD the dispatch order is: for every GROUP of `ngroup` column tiles, for
+// every row block of the XCD, the ngroup tiles of that block -- so the ~32 workgroups an XCD runs at a time share ONE
+// group's weight rows (ngroup x BN x K x 2 bytes, chosen <= 1.6 MB by the launcher) and that slice stays in L2 while
+// the row blocks stream past it.  With all column tiles in one group (the round-1/2 order) the whole weight matrix is
+// re-streamed for every row block once it exceeds the L2: 789 MB counted on the teacher's fc1 against 392 MB
+// algorithmic.  The price is one more read of the activation rows per extra group.
+__device__ __forceinline__ void gemm_tile_of(int lin, int tiles_n, int ngroup, int groups, int& mb, int& nb) {
+  const int xcd = lin & 7, idx = lin >> 3;
+  const int nbi = idx % ngroup;
+  const int rest = idx / ngroup;
+  const int mbl = rest % groups, ng = rest / groups;
+  mb = mbl * 8 + xcd;
+  nb = ng * ngroup + nbi;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel(const unsigned short*
                                                            const unsigned short* __restrict__ W,
                                                            const unsigned short* __restrict__ bias,
                                                            unsigned short* aux, unsigned short* __restrict__ Y,
-                                                           int M, int N, int K, int tiles_n, int mblocks) {
+                                                           int M, int N, int K, int tiles_n, int mblocks, int ngroup) {
   extern __shared__ __align__(16) unsigned char g_lds[];
   constexpr int A_BYTES = GBM * GBK * 2;          // 32 KiB
   constexpr int B_BYTES = BN * GBK * 2;
@@ -151,11 +167,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel(const unsigned short*
   static_assert(NSUB % 8 == 0, "every wave issues the same number of LDS-DMA pieces");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lin = blockIdx.x;
-  const int idx = lin >> 3;
-  const int mb = (idx / tiles_n) * 8 + (lin & 7);
+  int mb, nb;
+  gemm_tile_of(blockIdx.x, tiles_n, ngroup, (mblocks + 7) >> 3, mb, nb);
   if (mb >= mblocks) return;
-  const int nb = idx % tiles_n;
   const int m0 = mb * GBM, n0 = nb * BN;
   const int wm = wave >> 2, wn = wave & 3;
 
@@ -264,15 +278,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const unsigned shor
                                                              const unsigned short* __restrict__ W,
                                                              const unsigned short* __restrict__ bias,
                                                              unsigned short* aux, unsigned short* __restrict__ Y,
-                                                             int M, int N, int K, int tiles_n, int mblocks) {
+                                                             int M, int N, int K, int tiles_n, int mblocks, int ngroup) {
   extern __shared__ __align__(16) unsigned char g_lds[];
   constexpr int BN = 256, NT = 4, UNIT = 32768, NSLOT = 5;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lin = blockIdx.x;
-  const int idx = lin >> 3;
-  const int mb = (idx / tiles_n) * 8 + (lin & 7);
+  int mb, nb;
+  gemm_tile_of(blockIdx.x, tiles_n, ngroup, (mblocks + 7) >> 3, mb, nb);
   if (mb >= mblocks) return;
-  const int nb = idx % tiles_n;
   const int m0 = mb * GBM, n0 = nb * BN;
   const int wm = wave >> 2, wn = wave & 3;
 
@@ -362,15 +374,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const unsigned shor
   gemm_epilogue<BN, NT, EPI>(acc, g_lds, bias, aux, Y, M, N, m0, n0, wm, wn, lane, wave);
 }
 
+// column tiles per group (see gemm_tile_of): all of them if the weight matrix is small enough to live in an XCD's L2
+// next to the streaming activation rows, else the largest divisor of tiles_n whose weight slice is <= 1.6 MB -- unless
+// the activation rows are the big operand (K > N: fc2), where splitting the column tiles of a row block would re-read
+// the rows instead
+static int gemm_column_group(int tiles_n, int bn, int K) {
+  const double tile_bytes = (double)bn * K * 2.0;
+  if (tiles_n * tile_bytes <= 1.6e6 || K > tiles_n * bn) return tiles_n;
+  int best = 1;
+  for (int g = 1; g <= tiles_n; ++g)
+    if (tiles_n % g == 0 && g * tile_bytes <= 1.6e6) best = g;
+  return best;
+}
+
 template <int EPI>
 static void launch_gemm_ring(const void* x, const void* w, const void* bias, void* aux, void* y, int M, int N, int K,
                              hipStream_t st) {
   const int tiles_n = N / 256, mblocks = (M + GBM - 1) / GBM;
   const int groups = (mblocks + 7) / 8;
+  const int ngroup = gemm_column_group(tiles_n, 256, K);
   allow_full_lds((const void*)gemm_bf16_ring_kernel<EPI>);
   hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3(groups * tiles_n * 8), dim3(512), 5 * 32768, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
-                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks);
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup);
 }
 
 template <int BN, int EPI>
@@ -378,11 +404,12 @@ static void launch_gemm(const void* x, const void* w, const void* bias, void* au
                         hipStream_t st) {
   const int tiles_n = N / BN, mblocks = (M + GBM - 1) / GBM;
   const int groups = (mblocks + 7) / 8;
+  const int ngroup = gemm_column_group(tiles_n, BN, K);
   const size_t lds = 2 * (size_t)(GBM * GBK * 2 + BN * GBK * 2);
   allow_full_lds((const void*)gemm_bf16_nt_kernel<BN, EPI>);
   hipLaunchKernelGGL((gemm_bf16_nt_kernel<BN, EPI>), dim3(groups * tiles_n * 8), dim3(512), lds, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
-                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks);
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup);
 }
 
 }  // namespace basd
