@@ -237,7 +237,7 @@ def main():
                                       # run on a side stream / sweep data-dependent blocks)
                 # sweeps actually run by every matrix of the launch (the kernel returns them): the work DONE,
                 # not a nominal count -- the convergence test decides how many sweeps the algorithm needs
-                sw = float(sweeps_t.float().sum())
+                sw = float(sweeps_t.float().abs().sum())
                 flops += sw * (n * (n - 1) / 2) * 14.0 * m
                 sweep_sum += sw
                 mats += b

@@ -132,10 +132,13 @@ int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank,
  * the first `norm_rows` rows (norm_rows = m_rows normally; for a stacked
  * [A; I] input pass the row count of A so that the bottom block -- the
  * accumulated right singular vectors -- is excluded from the norm).
- * sweeps [batch] (optional, may be NULL) receives the sweeps used.
+ * sweeps [batch] (optional, may be NULL) receives the sweeps used, NEGATED if the matrix was still rotating when
+ * max_sweeps was reached (with max_sweeps = 1: "this visit still made a large rotation").
  * active (optional, device int32 [batch], may be NULL): matrix b has non-zero entries only in its
  * leading active[b] columns (and rows, if active_rows != 0); the sweeps then run over that
- * block only (rank-masked principal-angle problems, no host sync on the ranks).
+ * block only (rank-masked principal-angle problems, no host sync on the ranks).  active[b] < 0 skips matrix b
+ * altogether (w, sigma untouched, sweeps[b] = 0; register-resident single-matrix kernels, i.e. batch < 512 or tall /
+ * single-mailbox shapes): converged matrices of a block tournament cost a 5 us launch instead of a sweep.
  * status (optional, device int32 word, may be NULL): BASD_STATUS_NONCONVERGED / BASD_STATUS_NONFINITE are OR-ed in.
  * Requires n_cols <= 256, ld % 4 == 0 and either n_cols * ld * 4 + 4096 <= 160 KiB (matrix resident in LDS) or the
  * register-resident forms: m_rows <= 224, or m_rows <= 384 with n_cols <= 192 (tall block pairs; with max_sweeps = 1

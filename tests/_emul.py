@@ -123,9 +123,21 @@ def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True,
         w.copy_(torch.nan_to_num(w, nan=0.0, posinf=0.0, neginf=0.0))
         sigma.fill_(float("nan"))
         return sigma, torch.full((batch,), 1, dtype=torch.int32)
+    sweeps = torch.ones(batch, dtype=torch.int32)
     for b in range(batch):
+        if active is not None and int(active[b]) < 0:  # skipped matrix: untouched
+            sweeps[b] = 0
+            continue
         full = w[b, :, :m_rows].double().t()           # [m, n]
         top = full[:norm_rows]
+        # sweeps < 0: "still made a large rotation" = the input columns were not yet orthogonal to the kernel's
+        # quadratic-convergence threshold (pair |cos| 5e-4)
+        nrm_in = top.norm(dim=0)
+        if int((nrm_in > 0).sum()) > 1:
+            cn_in = top[:, nrm_in > 0] / nrm_in[nrm_in > 0]
+            off = (cn_in.t() @ cn_in - torch.eye(cn_in.shape[1], dtype=torch.float64)).abs().max()
+            if float(off) > 5e-4 and max_sweeps < 3:
+                sweeps[b] = -1
         u, s, vh = torch.linalg.svd(top, full_matrices=False)
         r = s.shape[0]
         out = torch.zeros(m_rows, n_cols, dtype=torch.float64)
@@ -146,7 +158,7 @@ def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True,
             out[norm_rows:, :r] = full[norm_rows:] @ vh.t()
         w[b, :, :m_rows] = out.t().float()
         sigma[b, :r] = s.float()
-    return sigma, torch.full((batch,), 1, dtype=torch.int32)
+    return sigma, sweeps
 
 
 def mp_rank(evals, rows, d, cap):

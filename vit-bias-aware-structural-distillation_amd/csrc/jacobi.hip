@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
     const int dst = s_rank[c];
     *reinterpret_cast<float4*>(src + (size_t)dst * ld + r) = reinterpret_cast<const float4*>(W)[i];
   }
-  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = used_sweeps;
+  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = converged ? used_sweeps : -used_sweeps;
   report_status(status, converged, s_sig, n, tid, nthreads);
 }
 
@@ -212,6 +212,11 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
   float* s_nrm = reinterpret_cast<float*>(s_id + 2 * 2 * 132);   // [NMAT][NBUF][132] squared norms travelling along
   int* s_flag = reinterpret_cast<int*>(s_nrm + 2 * 2 * 132);     // [2] any rotation, [2] any LARGE rotation
 
+  if (NMAT == 1 && active != nullptr && active[blockIdx.x] < 0) {
+    // skipped matrix (a block pair of a tournament whose matrix has already converged): nothing is read or written
+    if (sweeps_out && threadIdx.x == 0) sweeps_out[blockIdx.x] = 0;
+    return;
+  }
   float* src[NMAT];
   int n_act[NMAT], mrows[NMAT], n_e[NMAT], S[NMAT], idX[NMAT], idY[NMAT];
   bool live[NMAT];
@@ -439,7 +444,7 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
         }
       }
     }
-    if (sweeps_out && tid == 0) sweeps_out[mat] = used_sweeps;
+    if (sweeps_out && tid == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
     __syncthreads();
     report_status(status, converged, s_sig, n_tot, tid, blockDim.x);
   }
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
   }
-  if (sweeps_out && tid == 0) sweeps_out[mat] = used_sweeps;
+  if (sweeps_out && tid == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
   report_status(status, converged, s_sig, n_tot, tid, blockDim.x);
 }
 
@@ -752,6 +757,16 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     else if (oe_ch == 4) BASD_LAUNCH_OE(4, 2, grid2, lds_oe2);
     else BASD_LAUNCH_OE(6, 2, grid2, lds_oe2);
     return check_launch("jacobi_svd (odd-even x2)");
+  }
+  const size_t lds_single = (size_t)npairs * 32 * oe_ch * 4 + oe_scratch;            // NMAT 1, ONE mailbox
+  if (!fits && chunks <= 7 && npairs <= 128 && lds_single <= BASD_JACOBI_LDS_BYTES) {
+    // 193 .. 224 rows x up to 256 columns (the 196 x 196 token-side Procrustes cores of the wide students): the
+    // double-buffered mailbox does not fit, a single one does; still register-resident (the LDS-resident kernel below
+    // takes 7.7 ms for 512 such matrices)
+    allow_full_lds((const void*)jacobi_oe_kernel<7, 1, 1>);
+    hipLaunchKernelGGL((jacobi_oe_kernel<7, 1, 1>), dim3(batch), dim3(threads), lds_single, st, w, batch, m_rows, n_cols, ld,
+                       norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows, status);
+    return check_launch("jacobi_svd (odd-even, single mailbox)");
   }
   if (fits) {
     if (oe_ch == 2) BASD_LAUNCH_OE(2, 1, batch, lds_oe1);
