@@ -89,19 +89,22 @@ def _tournament_perms(nblk: int, device):
                  for r in range(1, len(rounds))]
         wrap = torch.tensor([inverse(rounds[-1])[blk] for blk in rounds[0]], dtype=torch.long, device=device)
         restore = torch.tensor(inverse(rounds[-1]), dtype=torch.long, device=device)
-        hit = _ROUND_CACHE[key] = (first, steps, wrap, restore)
-    first, steps, wrap, restore = hit
+        # pair p of round r holds the blocks rounds[r][2p], rounds[r][2p+1]; "siblings" = the blocks {2m, 2m+1}
+        sib = [torch.tensor([(r[2 * p] ^ 1) == r[2 * p + 1] for p in range(nblk // 2)], dtype=torch.bool, device=device)
+               for r in rounds]
+        hit = _ROUND_CACHE[key] = (first, steps, wrap, restore, sib)
+    first, steps, wrap, restore, sib = hit
 
     class _Perms:
-        """iterating yields the permutation to apply before each round; the first sweep starts from the natural
-        order, later sweeps from the last round's order"""
+        """iterating yields (the permutation to apply before the round, [npair] bool: the pair's blocks are siblings
+        {2m, 2m + 1}); the first sweep starts from the natural order, later sweeps from the last round's order"""
         def __init__(self):
             self.started = False
 
         def __iter__(self):
-            yield wrap if self.started else first
+            yield (wrap if self.started else first), sib[0]
             self.started = True
-            yield from steps
+            yield from zip(steps, sib[1:])
 
     return _Perms(), restore
 
@@ -157,16 +160,25 @@ def _psd_eig_blocked(a64: torch.Tensor):
         # permutation per round takes round r's order to round r + 1's.  A matrix whose every visit of one whole outer
         # sweep reported "no large rotation" (sweeps > 0) is finished: its pairs are skipped from then on (active = -1
         # costs a 5 us launch slot instead of a 0.4 ms sweep), all on the device -- no host sync.
+        # A pair with an all-zero block (columns beyond the numerical rank: the rank-masked principal-angle problems
+        # of a 384-wide student have rank ~160, i.e. two of their four blocks) is skipped too: rotating against zero
+        # columns is a no-op, and a round in which every pair of every matrix is skipped costs no sweep at all.  A
+        # matrix with ONE non-zero block still needs that block's own columns rotated: it is visited with its sibling.
         perms, restore = _tournament_perms(nblk, x.device)
         npair = nblk // 2
         cur = xv
         done = torch.zeros(b, dtype=torch.bool, device=x.device)
+        nz = (xv.abs().amax(dim=(2, 3)) > 0)                         # [b, nblk]: block holds a non-zero column
+        lone = (nz.sum(dim=1) == 1).unsqueeze(1)                      # [b, 1]
         full_cols = torch.full((b, npair), 2 * WIDE_BLOCK, dtype=torch.int32, device=x.device)
         for _ in range(WIDE_DIRECT_SWEEPS):
             quiet = torch.ones(b, dtype=torch.bool, device=x.device)
-            act = torch.where(done.unsqueeze(1), -1, full_cols).reshape(-1).contiguous()
-            for perm in perms:
+            for perm, siblings in perms:
                 cur = cur[:, perm].contiguous()                      # [b, nblk, 96, n_pad], pair p = blocks 2p, 2p + 1
+                nz = nz[:, perm]
+                nzp = nz.view(b, npair, 2)
+                work = (nzp.all(dim=2) | (lone & nzp.any(dim=2) & siblings.unsqueeze(0))) & ~done.unsqueeze(1)
+                act = torch.where(work, full_cols, -1).reshape(-1).contiguous()
                 _, sw = ops.jacobi_svd(cur.view(b * npair, 2 * WIDE_BLOCK, n_pad), n_pad, max_sweeps=1, sort=False,
                                        flag_status=False, active=act)
                 quiet &= (sw.view(b, npair) >= 0).all(dim=1)
