@@ -11,7 +11,8 @@ def timeit(f, it=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / it * 1e3
 
-for batch, n, rank in [(1024, 192, 192), (1024, 192, 120), (12, 192, 192), (4, 64, 64), (48, 100, 37)]:
+for batch, n, rank in [(1024, 192, 192), (1024, 192, 120), (12, 192, 192), (4, 64, 64), (48, 100, 37), (512, 196, 195),
+                       (512, 196, 120)]:
     g = torch.Generator().manual_seed(n + rank)
     z = torch.randn(batch, 2 * n, rank, dtype=torch.float64, generator=g) @ torch.randn(batch, rank, n, dtype=torch.float64, generator=g)
     a = (z.transpose(1, 2) @ z).cuda()

@@ -79,7 +79,7 @@ def test_jacobi_stacked_gives_consistent_right_vectors(nat):
     assert torch.allclose(v.transpose(1, 2) @ v, torch.eye(k, dtype=torch.float64).expand(4, k, k), atol=2e-6)
 
 
-@pytest.mark.parametrize("n,rank", [(32, 32), (32, 11), (192, 192), (192, 63)])
+@pytest.mark.parametrize("n,rank", [(32, 32), (32, 11), (192, 192), (192, 63), (196, 195), (196, 60), (194, 194)])
 def test_pchol_then_jacobi_is_an_eigensolver(nat, n, rank):
     g = torch.Generator().manual_seed(n + rank)
     x = torch.randn(3, 4 * n, rank, dtype=torch.float64, generator=g) * torch.logspace(0, -3, rank, dtype=torch.float64)
