@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the teacher forward of batch k + 1 with "
+                    "loss / backward of batch k (every step then starts with its own teacher forward)")
     args = ap.parse_args()
     student_preset, teacher_preset, img_size, patch, cfg_batch, F_STUDENT, F_TEACHER, workload = CONFIGS[args.config]
     if args.batch is None:
@@ -186,10 +188,16 @@ def main():
     probe_steps = eager_probe - 1
     graphed = False
     if not args.eager:
-        graphed = trainer.enable_graph(batch)
+        graphed = trainer.enable_graph(batch, pipeline=False if args.no_pipeline else None)
         progress(f"hipGraph capture: {'ok' if graphed else 'failed: ' + str(trainer.graph_error)}")
+
+    def batch_at(i):
+        return batches[i % len(batches)]
+
+    # train_step(batch, next_batch): with the pipelined captured step the teacher forward + statistics of the NEXT batch
+    # run on the side stream under loss / backward of this one (software pipelining; the warm-up steps fill the pipe)
     for i in range(args.warmup):
-        loss, _ = trainer.train_step(batches[i % len(batches)])
+        loss, _ = trainer.train_step(batch_at(i), batch_at(i + 1))
     torch.cuda.synchronize()
     progress(f"{args.warmup} warm-up steps done; timing {args.steps} steps")
 
@@ -206,7 +214,7 @@ def main():
     host_s = 0.0
     for i in range(args.steps):
         th = time.perf_counter()
-        loss, _ = trainer.train_step(batches[(args.warmup + i) % len(batches)])
+        loss, _ = trainer.train_step(batch_at(args.warmup + i), batch_at(args.warmup + i + 1))
         host_s += time.perf_counter() - th      # time to ENQUEUE a step (no device sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -218,6 +226,21 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
+    pipelined = trainer._pipe is not None
+    unpipelined = None
+    if pipelined and world == 1:
+        # the same K steps with every step waiting for its own teacher forward (the schedule of rounds 1 - 2), for
+        # reference: re-capture without the pipeline, re-warm, time
+        if trainer.enable_graph(batch, pipeline=False):
+            for i in range(max(args.warmup, 2)):
+                trainer.train_step(batch_at(i), None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                trainer.train_step(batch_at(args.warmup + i), None)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            unpipelined = {"ms_per_step": 1e3 * e1 / args.steps, "value": global_batch * args.steps / e1}
 
     if rank == 0:
         ks = timer.summary()
@@ -300,6 +323,12 @@ def main():
                          "tflops_if_whole_step": vit_flops / (ms_per_step / 1e3) / 1e12, "peak_bf16": 2500.0},
             "kernel_ms_per_step": {k: v["total_ms"] / probe_steps for k, v in ks.items()},
             "hip_graph": graphed, "hip_graph_error": trainer.graph_error,
+            "schedule": ("teacher forward + selector statistics of batch k+1 on a side stream under loss / backward of "
+                         "batch k (software pipelining across steps; every timed step still runs one teacher forward, one "
+                         "student forward / backward, one loss, one optimizer step; results equal the unpipelined "
+                         "schedule: tests/test_train_step_gpu.py)" if pipelined else
+                         "every step: [teacher forward || student forward] -> loss -> backward -> optimizer"),
+            "unpipelined": unpipelined,
             "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 2**30,
             "host_enqueue_ms_per_step": 1e3 * host_s / args.steps,
             "loss": float(loss),

@@ -41,6 +41,34 @@ def test_graph_replay_matches_eager():
     assert graphed.optimizer.k == 3
 
 
+def test_pipelined_teacher_steps_equal_unpipelined_steps():
+    """The captured step with the teacher pipelined ACROSS steps (teacher forward + statistics of batch k + 1 on the side
+    stream under loss / backward of batch k, two held sets) against the captured step that runs its own teacher forward
+    first, on the same sequence of three different batches: same losses, same weights after five steps -- including a
+    step whose ``next_batch`` promise is broken (the held set is then refilled, unpipelined)."""
+    from basd_amd.train import SyntheticLoader
+    out = {}
+    for pipe in (False, True):
+        trainer, _ = _make(32)
+        batches = [next(iter(SyntheticLoader(32, 32, 100, 1, "cuda", seed=50 + i))) for i in range(3)]
+        assert trainer.enable_graph(batches[0], pipeline=pipe), trainer.graph_error
+        assert (trainer._pipe is not None) == pipe
+        losses = []
+        order = [0, 1, 2, 0, 2]
+        for i, b in enumerate(order):
+            # step 3 announces batch 1 but step 4 brings batch 2
+            announced = batches[order[i + 1]] if i + 1 < len(order) and i != 3 else batches[1]
+            loss, _ = trainer.train_step(batches[b], announced)
+            losses.append(float(loss))
+        trainer.check_health()
+        out[pipe] = (losses, trainer.flat.data.clone())
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) <= 5e-3 * abs(b), (out[True][0], out[False][0])
+    assert abs(out[True][0][0] - out[False][0][0]) <= 1e-5 * abs(out[False][0][0])      # step 0: identical inputs
+    rel = float((out[True][1] - out[False][1]).norm() / out[False][1].norm())
+    assert rel < 2e-3, rel
+
+
 def test_c1_step_matches_the_cpu_oracle_step():
     """One BASELINE-c1-size step (DeiT-T / ViT-S, 32x32, patch 4) on the HIP path against the CPU restatement of the
     whole step (oracle/cpu_step.py: plain fp32 torch ViTs + the oracle loss pinned to the reference) on IDENTICAL
