@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--no-ab", action="store_true", help="skip the second, unpipelined measurement (profiling runs)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the teacher forward of batch k + 1 with "
                     "loss / backward of batch k (every step then starts with its own teacher forward)")
     args = ap.parse_args()
@@ -228,7 +229,7 @@ def main():
     value = global_batch * args.steps / elapsed
     pipelined = trainer._pipe is not None
     unpipelined = None
-    if pipelined and world == 1:
+    if pipelined and world == 1 and not args.no_ab:
         # the same K steps with every step waiting for its own teacher forward (the schedule of rounds 1 - 2), for
         # reference: re-capture without the pipeline, re-warm, time
         if trainer.enable_graph(batch, pipeline=False):
@@ -322,7 +323,7 @@ def main():
             "vit_gemm": {"algorithmic_tflop_per_step": vit_flops / 1e12,
                          "tflops_if_whole_step": vit_flops / (ms_per_step / 1e3) / 1e12, "peak_bf16": 2500.0},
             "kernel_ms_per_step": {k: v["total_ms"] / probe_steps for k, v in ks.items()},
-            "hip_graph": graphed, "hip_graph_error": trainer.graph_error,
+            "hip_graph": graphed, "hip_graph_error": trainer.graph_error, "pipeline_error": trainer.pipeline_error,
             "schedule": ("teacher forward + selector statistics of batch k+1 on a side stream under loss / backward of "
                          "batch k (software pipelining across steps; every timed step still runs one teacher forward, one "
                          "student forward / backward, one loss, one optimizer step; results equal the unpipelined "
