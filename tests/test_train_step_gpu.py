@@ -69,6 +69,23 @@ def test_pipelined_teacher_steps_equal_unpipelined_steps():
     assert rel < 2e-3, rel
 
 
+def test_pipeline_is_given_up_when_no_batch_is_ever_announced():
+    """a loop that calls train_step(batch) with a new batch every time and never says what comes next would run the
+    teacher twice per step: after two such misses the trainer re-captures the per-step schedule; a loop that repeats
+    one batch keeps the pipeline (the bet on "the same object again" holds)"""
+    from basd_amd.train import SyntheticLoader
+    trainer, batch = _make(32)
+    assert trainer.enable_graph(batch) and trainer._pipe is not None
+    for _ in range(4):
+        trainer.train_step(batch)
+    assert trainer._pipe is not None and trainer._pipe["blind"] == 0
+    others = [next(iter(SyntheticLoader(32, 32, 100, 1, "cuda", seed=70 + i))) for i in range(5)]
+    losses = [float(trainer.train_step(b)[0]) for b in others]
+    assert trainer._pipe is None and trainer._graph is not None
+    assert all(l == l for l in losses)
+    trainer.check_health()
+
+
 def test_c1_step_matches_the_cpu_oracle_step():
     """One BASELINE-c1-size step (DeiT-T / ViT-S, 32x32, patch 4) on the HIP path against the CPU restatement of the
     whole step (oracle/cpu_step.py: plain fp32 torch ViTs + the oracle loss pinned to the reference) on IDENTICAL

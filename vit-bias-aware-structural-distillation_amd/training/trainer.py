@@ -259,7 +259,8 @@ class Trainer:
             graphs.append(g)
             outs.append(out)
         # held[0] was overwritten by the warm-up / capture passes: nothing is valid until a step fills it
-        self._pipe = {"graphs": graphs, "out": outs, "held": held, "cur": 0, "valid_for": None}
+        self._pipe = {"graphs": graphs, "out": outs, "held": held, "cur": 0, "valid_for": None, "blind": 0,
+                      "announced": None}
 
     def enable_graph(self, batch: dict, warmup: int = 3, pipeline: bool | None = None) -> bool:
         """Capture teacher fwd + student fwd + loss + backward into ONE hipGraph (static input
@@ -387,6 +388,10 @@ class Trainer:
             self.optimizer.step()
             self.optimizer.zero_grad()
             return loss, logits
+        if self._pipe is not None and self._pipe["valid_for"] is not clean and self._pipe["blind"] >= 2:
+            # a caller that never announces the next batch and never repeats one pays a second, unpipelined teacher
+            # pass per step: give the pipeline up and capture the per-step schedule instead
+            self.enable_graph({"clean": clean, "augmented": batch["augmented"], "label": targets}, pipeline=False)
         if self._pipe is not None:
             pipe = self._pipe
             cur = pipe["cur"]
@@ -394,10 +399,14 @@ class Trainer:
                 # first step, or the sequence was broken: the teacher branch of THIS batch runs now, unpipelined
                 with torch.no_grad():
                     self._held_copy(pipe["held"][cur], self._teacher_branch(clean))
-            upcoming = None
+                pipe["blind"] += int(pipe["announced"] is False)
+            else:
+                pipe["blind"] = 0
+            upcoming = clean                      # nothing announced: bet on the same batch object coming again
+            pipe["announced"] = next_batch is not None
             if next_batch is not None and next_batch["clean"].shape == self._g_clean_next.shape:
                 upcoming = next_batch["clean"]
-            self._g_clean_next.copy_(clean if upcoming is None else upcoming)
+            self._g_clean_next.copy_(upcoming)
             if student_imgs is not self._g_imgs:
                 self._g_imgs.copy_(student_imgs)
             if mixed_targets is not self._g_targets:
