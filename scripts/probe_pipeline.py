@@ -58,17 +58,26 @@ def main():
             return _extract_student(trainer.model, batch["augmented"], trainer.basd_loss.token_layers,
                                     layer_paths=trainer._student_layer_paths, has_cls_token=trainer._student_has_cls)
 
-    def piped():
+    def piped(split=None):
+        """split = j: the side stream pauses after teacher block j until the main stream has finished the loss
+        FORWARD (the GPU-filling Jacobi launch of the Procrustes cores), then continues under the backward"""
         trainer.flat.refresh_bf16()
         cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            tn, _ = extract_intermediates(trainer._teacher, batch2["clean"])      # teacher of the NEXT batch
-            sel.precompute_teacher(tn)
-            sel._frames = None
+        start = torch.cuda.Event()
+        start.record()
         sel._frames = (held_frames[0], dict(held_frames[1]))
         logits, s_tokens = student_forward()
         loss = trainer.basd_loss(logits.float(), targets, s_tokens, held_tokens, held_imp)
+        fwd_done = torch.cuda.Event()
+        fwd_done.record()
+        side.wait_event(start)
+        with torch.cuda.stream(side):
+            def on_layer(j, _t):
+                if split is not None and j == split:
+                    side.wait_event(fwd_done)
+            tn, _ = extract_intermediates(trainer._teacher, batch2["clean"], on_layer=on_layer)
+            sel.precompute_teacher(tn)
+            sel._frames = None
         loss.backward()
         cur.wait_stream(side)
         return loss.detach()
@@ -77,7 +86,9 @@ def main():
         return trainer._forward_backward(batch["clean"], batch["augmented"], targets)[0]
 
     results = {}
-    for name, fn in (("plain", plain), ("pipelined", piped)):
+    variants = [("plain", plain), ("pipelined", piped)]
+    variants += [(f"pipelined, pause after block {j}", (lambda j=j: piped(j))) for j in (1, 3, 5, 7, 9)]
+    for name, fn in variants:
         trainer.reducer.paused = True
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream())
@@ -107,6 +118,8 @@ def main():
         print(f"{name}: {results[name]:.2f} ms per step (loss {float(out):.4f})", flush=True)
     print(f"pipelining the teacher across steps: {results['plain'] - results['pipelined']:+.2f} ms "
           f"({100 * (results['plain'] / results['pipelined'] - 1):+.1f} % images/s)")
+    best = min(results, key=results.get)
+    print(f"best schedule: {best} ({results[best]:.2f} ms)")
 
 
 if __name__ == "__main__":
