@@ -113,3 +113,50 @@ def test_bf16_tokens_close_to_fp32_path():
     torch.testing.assert_close(a["weights"], b["weights"], atol=1e-6, rtol=0)
     for l in inputs["token_layers"]:
         assert rel_l2(b[f"grad_student_{l}"], a[f"grad_student_{l}"]) < 8e-3   # bf16 rounding of the grad
+
+
+@pytest.mark.parametrize("name,B,N,d_s,d_t", [("c4", 128, 196, 384, 1024), ("c5", 256, 196, 768, 1280),
+                                              ("c2", 256, 196, 192, 768)])
+def test_procrustes_invariances_at_full_bench_size(name, B, N, d_s, d_t):
+    """Size-independent properties of the attention-weighted Procrustes term at the FULL per-GPU sizes of BASELINE c2 /
+    c4 / c5 (E = 4 extraction points: 512 - 1024 cores per launch chain; the goldens pin c4 / c5 only at batch 8 / 4):
+    (i) the value does not change when the student's or the teacher's feature space is rotated (the nuclear norm of
+    the cross-covariance is orthogonally invariant); (ii) a teacher that IS a rotated copy of the student (an isometry
+    into the wider space) has distance 0, and the gradient with respect to the student vanishes there."""
+    import basd_amd._native as native
+    from basd_amd.losses import functional as BF
+    E = 4
+    g = torch.Generator().manual_seed(B + d_s)
+    dev = "cuda"
+
+    def orth(n):
+        q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+        return q.float().to(dev)
+
+    students = [(torch.randn(B, N, d_s, generator=g) * torch.logspace(0, -1.5, d_s)).to(dev) for _ in range(E)]
+    t_all = (torch.randn(E, B, N, d_t, generator=g) * torch.logspace(0, -1.5, d_t)).to(dev)
+    imp = (torch.rand(E, B, N, generator=g) + 0.1).to(dev)
+    s_base = [s.clone().requires_grad_(True) for s in students]
+    base = BF.procrustes_all(s_base, t_all, imp)
+    base.sum().backward()
+    g_generic = max(float(s.grad.abs().max()) for s in s_base)          # gradient scale at an unrelated teacher
+    base = base.detach()
+    native.check_status()
+    assert base.shape == (E, B) and bool(torch.isfinite(base).all()) and bool((base > 0).all())
+    q_s, q_t = orth(d_s), orth(d_t)
+    rot_s = BF.procrustes_all([s @ q_s for s in students], t_all, imp)
+    rot_t = BF.procrustes_all(students, t_all @ q_t, imp)
+    native.check_status()
+    scale = base.abs().mean()
+    assert float((rot_s - base).abs().max() / scale) < 5e-5
+    assert float((rot_t - base).abs().max() / scale) < 5e-5
+    # (ii) teacher = student rotated into the first d_s of the d_t teacher dimensions
+    iso = q_t[:d_s]                                             # [d_s, d_t], orthonormal rows
+    s_req = [s.clone().requires_grad_(True) for s in students]
+    twin = torch.stack([s.detach() @ iso for s in s_req])
+    zero = BF.procrustes_all(s_req, twin, imp)
+    native.check_status()
+    assert float(zero.detach().abs().max() / scale) < 2e-5
+    zero.sum().backward()
+    gmax = max(float(s.grad.abs().max()) for s in s_req)
+    assert gmax < 2e-3 * g_generic, (gmax, g_generic)
