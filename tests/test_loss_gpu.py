@@ -160,3 +160,46 @@ def test_procrustes_invariances_at_full_bench_size(name, B, N, d_s, d_t):
     zero.sum().backward()
     gmax = max(float(s.grad.abs().max()) for s in s_req)
     assert gmax < 2e-3 * g_generic, (gmax, g_generic)
+
+
+def test_whole_loss_is_invariant_to_the_order_of_the_batch_at_c2_size():
+    """BASDLoss at the benchmarked size (256 images, DeiT-T / ViT-B shapes): permuting the samples of the batch
+    (student tokens, teacher tokens, importance, logits, targets alike) leaves the Gram statistics, hence ranks and
+    mixing weights, and the total loss unchanged, and permutes the student gradients -- a checksum over the whole
+    selector + Procrustes + CE chain at the size the goldens cover with one fixture only."""
+    import types
+    import basd_amd._native as native
+    from basd_amd.losses import BASDLoss
+    B, N, d_s, d_t, L, C = 256, 196, 192, 768, 12, 1000
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)
+    mod = BASDLoss(torch.nn.CrossEntropyLoss(label_smoothing=0.1), d_s, d_t, 12, N,
+                   config=types.SimpleNamespace(num_extraction_points=4), teacher_has_cls_token=True).cuda()
+    base = torch.randn(B, N, 64, generator=g)                     # shared low-rank content: ranks well below 192
+    mix_s = [torch.randn(64, d_s, generator=g) / 8 for _ in mod.token_layers]
+    mix_t = [torch.randn(64, d_t, generator=g) / 8 for _ in range(L)]
+    s_tok = {l: (base @ m + 0.05 * torch.randn(B, N, d_s, generator=g)).cuda() for l, m in zip(mod.token_layers, mix_s)}
+    t_tok = {j: (base @ m + 0.05 * torch.randn(B, N, d_t, generator=g)).cuda() for j, m in enumerate(mix_t)}
+    t_imp = {j: (torch.rand(B, N, generator=g) + 0.05).cuda() for j in range(L)}
+    logits = torch.randn(B, C, generator=g).cuda()
+    targets = torch.randint(C, (B,), generator=g).cuda()
+    perm = torch.randperm(B, generator=g).cuda()
+
+    def run(order):
+        s_in = {l: v[order].clone().requires_grad_(True) for l, v in s_tok.items()}
+        lg = logits[order].clone().requires_grad_(True)
+        loss = mod(lg, targets[order], s_in, {j: v[order] for j, v in t_tok.items()},
+                   {j: v[order] for j, v in t_imp.items()})
+        loss.backward()
+        native.check_status()
+        ranks = dict(mod.layer_selector.subspace_ranks)
+        return float(loss.detach()), ranks, {l: v.grad for l, v in s_in.items()}, lg.grad
+
+    ident = torch.arange(B, device="cuda")
+    l0, r0, g0, gl0 = run(ident)
+    l1, r1, g1, gl1 = run(perm)
+    assert r0 == r1 and min(r0.values()) >= 1
+    assert abs(l1 - l0) <= 2e-5 * abs(l0), (l0, l1)
+    for l in g0:
+        assert rel_l2(g1[l], g0[l][perm]) < 3e-4, (l, rel_l2(g1[l], g0[l][perm]))
+    assert rel_l2(gl1, gl0[perm]) < 2e-5
