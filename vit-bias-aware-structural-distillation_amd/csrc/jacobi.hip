@@ -190,6 +190,30 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define BASD_JACOBI_QUAD 5.0e-4f
 #define BASD_JACOBI_QUAD_TAN 1.0e-2f
 
+// x' = x - s (y + tau x),  y' = y + s (x - tau y)  on four rows of a column pair, IN PLACE.  Written as C++ inside the
+// `if (rotate)` of the kernels below, the compiler computes the new columns into fresh registers and moves all of them
+// back at the merge point (52 v_mov per rotation of 2 x 24 values: a quarter of a rotation's VALU issue cycles, and
+// these kernels are VALU-issue-bound); with the outputs tied to the inputs there is nothing to move.  One register
+// pair {tau, s} feeds every FMA: op_sel broadcasts one half, neg_lo / neg_hi negate it.
+typedef float v2f_rot __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rotate_in_place(v4f& xa, v4f& ya, float tau, float s) {
+  const v2f_rot ts = {tau, s};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    v2f_rot x = h ? (v2f_rot){xa.z, xa.w} : (v2f_rot){xa.x, xa.y};
+    v2f_rot y = h ? (v2f_rot){ya.z, ya.w} : (v2f_rot){ya.x, ya.y};
+    v2f_rot t1, t2;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t1) : "v"(ts), "v"(x), "v"(y));                  // y + tau x
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        : "=v"(t2) : "v"(ts), "v"(y), "v"(x));                                                                   // x - tau y
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        : "+v"(x) : "v"(ts), "v"(t1));                                                                           // x - s t1
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(y) : "v"(ts), "v"(t2));          // y + s t2
+    if (h) { xa.z = x.x; xa.w = x.y; ya.z = y.x; ya.w = y.y; }
+    else { xa.x = x.x; xa.y = x.y; ya.x = y.x; ya.y = y.y; }
+  }
+}
+
 // NBUF = 2 double-buffers the mailbox (one barrier per step); NBUF = 1 halves its LDS footprint for a second
 // barrier per step: what lets columns of up to 384 rows (MAXCH = 12: the block pairs of the D_s = 384 eigensolver,
 // 96 slots x 1.5 KiB = 147 KiB) stay register-resident.
@@ -301,15 +325,7 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
             nX[mi] = fmaf(-tt, gamma, alpha);
             nY[mi] = fmaf(tt, gamma, beta);
 #pragma unroll
-            for (int ch = 0; ch < MAXCH; ++ch) {
-              const v4f x = X[mi][ch], y = Y[mi][ch];
-              v4f nx, ny;
-              nx.x = fmaf(-s, fmaf(tau, x.x, y.x), x.x); ny.x = fmaf(s, fmaf(-tau, y.x, x.x), y.x);
-              nx.y = fmaf(-s, fmaf(tau, x.y, y.y), x.y); ny.y = fmaf(s, fmaf(-tau, y.y, x.y), y.y);
-              nx.z = fmaf(-s, fmaf(tau, x.z, y.z), x.z); ny.z = fmaf(s, fmaf(-tau, y.z, x.z), y.z);
-              nx.w = fmaf(-s, fmaf(tau, x.w, y.w), x.w); ny.w = fmaf(s, fmaf(-tau, y.w, x.w), y.w);
-              X[mi][ch] = nx; Y[mi][ch] = ny;
-            }
+            for (int ch = 0; ch < MAXCH; ++ch) rotate_in_place(X[mi][ch], Y[mi][ch], tau, s);
           }
         }
       }
@@ -527,15 +543,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       na = fmaf(-t, g, al);
       nb_ = fmaf(t, g, be);
 #pragma unroll
-      for (int ch = 0; ch < MAXCH; ++ch) {
-        const v4f x = A[ch], y = B[ch];
-        v4f nx, ny;
-        nx.x = fmaf(-sn, fmaf(u, x.x, y.x), x.x); ny.x = fmaf(sn, fmaf(-u, y.x, x.x), y.x);
-        nx.y = fmaf(-sn, fmaf(u, x.y, y.y), x.y); ny.y = fmaf(sn, fmaf(-u, y.y, x.y), y.y);
-        nx.z = fmaf(-sn, fmaf(u, x.z, y.z), x.z); ny.z = fmaf(sn, fmaf(-u, y.z, x.z), y.z);
-        nx.w = fmaf(-sn, fmaf(u, x.w, y.w), x.w); ny.w = fmaf(sn, fmaf(-u, y.w, x.w), y.w);
-        A[ch] = nx; B[ch] = ny;
-      }
+      for (int ch = 0; ch < MAXCH; ++ch) rotate_in_place(A[ch], B[ch], u, sn);
     }
   };
   auto rot2 = [&](v4f (&A0)[MAXCH], v4f (&B0)[MAXCH], float& na0, float& nb0, v4f (&A1)[MAXCH], v4f (&B1)[MAXCH],
