@@ -286,8 +286,8 @@ def main():
                     # the contract's vocabulary has "hbm" | "mfma" only; this kernel is VALU-issue-bound and is priced
                     # against the fp32 vector peak, which equals the fp32 MFMA peak on gfx950 (157.3 TF)
                     "bound": "mfma", "bound_detail": "fp32 VALU kernel priced against the fp32 vector peak (= fp32 MFMA peak, 157.3 TF/s); "
-                    "limited by the per-step hand-over chain of its 6 waves (SQ counters: 48 % of wave cycles issuing, 32 % "
-                    "waiting on the hand-over; 25 % fewer VALU instructions per rotation left the time unchanged)",
+                    "VALU-issue-bound (one workgroup per CU runs it as fast as two; 57 v_pk_fma_f32 + 22 v_fmac + ~20 other "
+                    "VALU instructions per rotation and wave) plus the hand-over chain of its 6 waves",
                     "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                     "frac": achieved / 157.3, "traffic": traffic,
                     "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / probe_steps,
