@@ -25,6 +25,7 @@ namespace basd {
 typedef float gf32x4 __attribute__((ext_vector_type(4)));
 typedef short gbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short gu16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GBM = 256;   // tile rows (m)
 constexpr int GBK = 64;    // K step
@@ -374,6 +375,297 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const unsigned shor
   gemm_epilogue<BN, NT, EPI>(acc, g_lds, bias, aux, Y, M, N, m0, n0, wm, wn, lane, wave);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register -> global epilogue (no LDS).  The accumulator tile [n][m] of a wave holds, per 16-row block j and lane
+// (row r16 = lane & 15, q = lane >> 4), the columns i * 16 + 4 q + r of the wave's 64 (i = 0..3 n tiles, r = 0..3): four
+// 8-byte chunks 32 bytes apart.  Two register <-> lane butterflies (v_permlane32_swap on the pairs (i, i ^ 1), then
+// v_permlane16_swap on the same pairs) exchange the bits (i0, q1, q0) cyclically: afterwards lane q'' = 2 i0 + q1 owns
+// the columns h * 32 + q'' * 8 + [0, 8) for h = 0, 1, i.e. two 16-byte pieces, and one dwordx4 store instruction of the
+// wave writes 16 rows x 64 contiguous bytes.  16 swaps per row block; bias / GELU / the saved pre-activation are applied
+// in that final layout (16-byte loads).  Leaves the LDS ring alone, so the operands of the NEXT tile keep streaming in.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_direct(gf32x4 (&acc)[4][8], const unsigned short* bias,
+                                                     unsigned short* aux, unsigned short* Y, int M, int N, int row0,
+                                                     int col0, int lane) {
+  typedef unsigned int eu32x2 __attribute__((ext_vector_type(2)));
+  const int q = lane >> 4, r16 = lane & 15;
+  float bv[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv[h][k] = 0.f;
+  if ((EPI == 1 || EPI == 2 || EPI == 3) && bias != nullptr) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint4 b8 = *reinterpret_cast<const uint4*>(bias + col0 + h * 32 + q * 8);
+      const unsigned int w4[4] = {b8.x, b8.y, b8.z, b8.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bv[h][2 * k] = __uint_as_float(w4[k] << 16);
+        bv[h][2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u);
+      }
+    }
+  }
+  auto pack2 = [](float lo, float hi) -> unsigned int {
+    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v[4][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        eu32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[2 * p][j][r]),
+                                                     __float_as_uint(acc[2 * p + 1][j][r]), false, false);
+        eu32x2 s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+        v[2 * p][r] = __uint_as_float(s2[0]);
+        v[2 * p + 1][r] = __uint_as_float(s2[1]);
+      }
+    const int row = row0 + j * 16 + r16;
+    if (row < M) {
+      const size_t off = (size_t)row * N + col0 + q * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = v[2 * h + (k >> 2)][k & 3] + bv[h][k];
+        if (EPI == 2) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
+        }
+        if (EPI == 4) {
+          const uint4 p8 = *reinterpret_cast<const uint4*>(aux + off + h * 32);
+          const unsigned int w4[4] = {p8.x, p8.y, p8.z, p8.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            f[2 * k] *= gelu_erf_grad(__uint_as_float(w4[k] << 16));
+            f[2 * k + 1] *= gelu_erf_grad(__uint_as_float(w4[k] & 0xffff0000u));
+          }
+        }
+        uint4 o = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+        if (EPI == 3) {
+          __builtin_nontemporal_store((gu32x4){o.x, o.y, o.z, o.w}, reinterpret_cast<gu32x4*>(aux + off + h * 32));   // pre-activation, rounded
+          const unsigned int w4[4] = {o.x, o.y, o.z, o.w};
+          unsigned int g4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            g4[k] = pack2(gelu_erf(__uint_as_float(w4[k] << 16)), gelu_erf(__uint_as_float(w4[k] & 0xffff0000u)));
+          o = make_uint4(g4[0], g4[1], g4[2], g4[3]);
+        }
+        __builtin_nontemporal_store((gu32x4){o.x, o.y, o.z, o.w}, reinterpret_cast<gu32x4*>(Y + off + h * 32));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PERSISTENT ring kernel.  One workgroup per CU; the LDS ring of five 32 KiB units never drains: the last two K steps
+// of a tile already issue the first units of the NEXT one, the epilogue goes register -> global
+// (gemm_epilogue_direct), so the next tile's operands land while the epilogue runs.  The non-persistent ring kernel
+// pays, per tile, a cold prologue (the first operands: an L2 / HBM round trip with nothing to multiply), the LDS-staged
+// epilogue, the store drain before the workgroup can retire and the launch of its successor: 10.9 us against 17.5 us of
+// K loop at K = 768.
+//
+// Work split (per XCD x = blockIdx.x & 7: the P = gridDim.x / 8 workgroups with that residue share one L2 and own the
+// row blocks mb = x (mod 8): rb of them, n = rb * tiles_n tiles in the locality order q of gemm_tile_of -- q walks the
+// column tiles of a group fastest, then the row blocks).  Workgroup i of the XCD takes block i = the tiles {r P + i} plus
+// at most one of the n mod P remainder tiles: at any time the P workgroups multiply P NEIGHBOURING tiles at the SAME K
+// step, so a weight slice / activation row block read by several of them comes from HBM once and from L2 otherwise.
+// (Measured and rejected: stream-K ranges of equal length per workgroup -- 2.31 tiles per CU instead of 3 for a third of
+// the CUs on ViT-B's fc2 -- put the workgroups of an XCD at different K steps; what the balance won, the lost L2
+// sharing took back: 221 vs 226 us.)
+//
+// In lock-step all 256 CUs also reach their epilogues together (32 MB of stores at once); the first wait on an operand
+// issued behind those stores (two K steps into the next tile: vmcnt retires in order) then costs 3 800 - 9 100 stamped
+// cycles per tile.  Also measured and rejected: running XCD x a fraction x / 8 of a tile out of phase (every workgroup
+// parks the tail part of its first tile in a workspace and finishes that tile last): the parking round trip cost more
+// than the smoother stores saved (fc1 305 vs 293 us, proj 90 vs 68).  Non-temporal stores of the output keep it out of
+// the L2 the operands live in (1 - 2 %).
+// Operand addresses are an SGPR base (tile, K step) + a 32-bit per-lane offset that does not depend on the tile: eight
+// VGPRs instead of sixteen 64-bit pointers, and the next tile costs scalar arithmetic only.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned short* __restrict__ X,
+                                                              const unsigned short* __restrict__ W,
+                                                              const unsigned short* __restrict__ bias,
+                                                              unsigned short* aux, unsigned short* __restrict__ Y,
+                                                              int M, int N, int K, int tiles_n, int mblocks, int ngroup) {
+  extern __shared__ __align__(16) unsigned char g_lds[];
+  constexpr int NT = 4, UNIT = 32768, NSLOT = 5;
+  constexpr int NST = (EPI == 3) ? 32 : 16;                 // global stores of a wave per epilogue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nk = K / GBK;                                   // >= 3 (launcher)
+
+  // ---- this workgroup's range of the XCD's stream
+  const int xcd = blockIdx.x & 7, ci = blockIdx.x >> 3, P = gridDim.x >> 3;
+  const int rb = (mblocks - xcd + 7) >> 3;                  // >= 1 (launcher: mblocks >= 8)
+  const int n_x = rb * tiles_n, R0 = n_x / P, rem = n_x - R0 * P;
+  auto block_pos = [&](int b) { return b * R0 + (b * rem + P - 1) / P; };      // position of block b's first tile
+  auto tile_at = [&](int o, int& m0_, int& n0_) {           // o-th tile of this workgroup's block -> tile origin
+    const int q = o < R0 ? o * P + ci : R0 * P + (ci * rem + P - 1) / P;
+    const int nbi = q % ngroup, rest = q / ngroup;
+    const int mbl = rest % rb, ng = rest / rb;
+    m0_ = (mbl * 8 + xcd) * GBM;
+    n0_ = (ng * ngroup + nbi) * 256;
+  };
+  const int ntiles = block_pos(ci + 1) - block_pos(ci);     // R0 or R0 + 1 (>= 1: launcher)
+  int o = 0;                                                // tile of the block being multiplied
+
+  // ---- per-lane byte offsets of the LDS-DMA pieces inside a tile's operand panel (row pitch K): piece j of a unit
+  //      is sub-tile s = wave + 8 j: row block s >> 1, k block s & 1
+  const int q_dma = gemm_swz(lane * 16);
+  const int dma_row = q_dma >> 6, dma_c16 = (q_dma >> 4) & 3;
+  unsigned int off_a[4], off_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int s = wave + 8 * j;
+    off_b[j] = (unsigned int)((((s >> 1) * 16 + dma_row) * K + (s & 1) * 32 + dma_c16 * 8) * 2);
+  }
+  auto set_off_a = [&](int m0_) {                           // ragged last row block: rows beyond M re-read row M - 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = wave + 8 * j;
+      int m = m0_ + (s >> 1) * 16 + dma_row;
+      m = m < M ? m : M - 1;
+      off_a[j] = (unsigned int)(((m - m0_) * K + (s & 1) * 32 + dma_c16 * 8) * 2);
+    }
+  };
+  // SGPR base + 32-bit lane offset (the saddr form: hipcc widens the offsets to 64-bit VGPR pairs and adds them on the
+  // VALU when this is written with the builtin).  Inline asm: M0 saved / restored around the statement, the nops cover
+  // SALU-written base -> VMEM read (5 states) and M0 write -> LDS-DMA; the compiler does not count these loads (wanted:
+  // every wait on them below is a hand-counted vmcnt).
+  const unsigned int lds_base = (unsigned int)(size_t)g_lds;
+  auto issue_piece = [&](const unsigned char* base_u, unsigned int off, int slot, int j) {
+    const unsigned int dst = lds_base + slot * UNIT + (wave + 8 * j) * 1024;
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_nop 3\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base_u), "s"(dst) : "memory");
+  };
+  auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
+
+  gf32x4 acc[NT][8];
+  const int frag_off = gemm_swz((lane & 15) * 64 + (lane >> 4) * 16);
+  const int a_sub0 = (wm * 8) * 2, b_sub0 = (wn * NT) * 2;
+
+  // ---- one K step (64 deep = two k-blocks of 32), software-pipelined through registers so that no MFMA group waits
+  // for an LDS read issued just before it (with the reads in front of each k-block all eight waves stall together on
+  // a 96 KiB read burst right behind the barrier).  With W0 / W1 = the weight fragments of the two k-blocks, X0 / X1
+  // [0..7] the activation fragments, unit slots s (A), s+1 (B), and the next step's units in s+2, s+3:
+  //   entry:  wa = W0, x[0..3] = X0[0..3]            (read during the previous step, behind its barrier)
+  //   kb0:    x[4..7] <- X0[4..7] | 16 MFMAs wa x[0..3] | wb <- W1, x[0..3] <- X1[0..3] | 16 MFMAs wa x[4..7] + the four
+  //           LDS-DMA pieces of the A unit two steps ahead (slot s+4: the previous step's B slot)
+  //   kb1:    x[4..7] <- X1[4..7] | 16 MFMAs wb x[0..3] | WAIT: lgkmcnt(0), vmcnt: the next step's units have landed;
+  //           BARRIER: everybody's have, and everybody has read this step completely | wa <- W0', x[0..3] <- X0'[0..3]
+  //           of the NEXT step | 16 MFMAs wb x[4..7] + the four pieces of the B unit two steps ahead (slot s: this
+  //           step's A slot, free since the barrier)
+  // ONE instance of this code in the kernel (a single loop over segments and K steps, every step issues): with peeled
+  // variants the accumulators went through 128-register phi webs and spilled.
+  gbf16x8 xf[8], wa[NT], wb[NT];
+  auto read_w = [&](gbf16x8 (&w)[NT], int slot, int kb) {
+    const unsigned char* base = g_lds + slot * UNIT + frag_off;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) w[i] = *reinterpret_cast<const gbf16x8*>(base + (b_sub0 + i * 2 + kb) * 1024);
+  };
+  auto read_x = [&](int j0, int slot, int kb) {
+    const unsigned char* base = g_lds + slot * UNIT + frag_off;
+#pragma unroll
+    for (int j = j0; j < j0 + 4; ++j) xf[j] = *reinterpret_cast<const gbf16x8*>(base + (a_sub0 + j * 2 + kb) * 1024);
+  };
+  // 16 MFMAs w[0..3] x xf[j0..j0+3]; before_group(i) runs in front of MFMA group i, after_first() behind group 0
+  auto half = [&](gbf16x8 (&w)[NT], int j0, auto&& after_first, auto&& before_group) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      before_group(i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = j0; j < j0 + 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i], xf[j], acc[i][j], 0, 0, 0);
+      if (i == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        after_first();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto nothing = []() {};
+  auto nothing_i = [](int) {};
+
+  // ---- first segment
+  int m0, n0;
+  tile_at(0, m0, n0);
+  const unsigned char* a_cur = reinterpret_cast<const unsigned char*>(X) + (size_t)m0 * K * 2;
+  const unsigned char* b_cur = reinterpret_cast<const unsigned char*>(W) + (size_t)n0 * K * 2;
+  set_off_a(m0);
+  // ---- prologue: the units A, B of the first two steps into slots 0..3; the first step's fragments into registers
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_piece(((u & 1) ? b_cur : a_cur) + (u >> 1) * (GBK * 2), (u & 1) ? off_b[j] : off_a[j], u, j);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_w(wa, 1, 0);
+  read_x(0, 0, 0);
+  int slot = 0;
+  int st_pending = 0;                                       // stores issued behind the youngest LDS-DMA unit (counted waits)
+#pragma nounroll
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+    const bool has_next = o + 1 < ntiles;
+    // the tile whose first units the last two K steps issue; behind the last tile they re-read this tile's first K steps
+    // into ring slots nobody multiplies (keeps every step identical; drained before the kernel ends)
+    int m0n = m0, n0n = n0;
+    if (has_next) tile_at(o + 1, m0n, n0n);
+    const unsigned char* a_nxt = reinterpret_cast<const unsigned char*>(X) + (size_t)m0n * K * 2;
+    const unsigned char* b_nxt = reinterpret_cast<const unsigned char*>(W) + (size_t)n0n * K * 2;
+#pragma nounroll
+    for (int t = 0; t < nk; ++t) {
+      if (t == nk - 2) set_off_a(m0n);                      // every A unit of this tile has been issued
+      const unsigned char* a_src = t + 2 < nk ? a_cur + (t + 2) * (GBK * 2) : a_nxt + (t + 2 - nk) * (GBK * 2);
+      const unsigned char* b_src = t + 2 < nk ? b_cur + (t + 2) * (GBK * 2) : b_nxt + (t + 2 - nk) * (GBK * 2);
+      const int s_b = wrap(slot + 1), s_a1 = wrap(slot + 2), s_b1 = wrap(slot + 3), s_a2 = wrap(slot + 4);
+      // ---- k-block 0
+      half(wa, 0, [&]() { read_x(4, slot, 0); }, nothing_i);
+      read_w(wb, s_b, 1);
+      read_x(0, slot, 1);
+      half(wa, 4, nothing, [&](int i) { issue_piece(a_src, off_a[i], s_a2, i); });
+      // ---- k-block 1
+      half(wb, 0, [&]() { read_x(4, slot, 1); }, nothing_i);
+      // units of step t + 1: everything but the youngest unit (the A unit just issued) -- and, on the first step behind
+      // an epilogue, its st_pending stores, which were issued before that unit
+      if (t == 0 && st_pending != 0) {
+        if (NST == 16) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      read_w(wa, s_b1, 0);
+      read_x(0, s_a1, 0);
+      half(wb, 4, nothing, [&](int i) { issue_piece(b_src, off_b[i], slot, i); });
+      slot = s_a1;
+    }
+    const bool full_rows = m0 + GBM <= M;                   // every store of the epilogue is issued by every wave
+    gemm_epilogue_direct<EPI>(acc, bias, aux, Y, M, N, m0 + wm * 128, n0 + wn * 64, lane);
+    st_pending = full_rows ? NST : 0;
+    if (!full_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ragged rows: not every wave issues every store
+    if (!has_next) break;
+    ++o;
+    m0 = m0n;
+    n0 = n0n;
+    a_cur = a_nxt;
+    b_cur = b_nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing LDS-DMA pieces must not outlive the workgroup
+}
+
 // column tiles per group (see gemm_tile_of): all of them if the weight matrix is small enough to live in an XCD's L2
 // next to the streaming activation rows, else the largest divisor of tiles_n whose weight slice is <= 1.6 MB -- unless
 // the activation rows are the big operand (K > N: fc2), where splitting the column tiles of a row block would re-read
@@ -395,6 +687,27 @@ static void launch_gemm_ring(const void* x, const void* w, const void* bias, voi
   const int ngroup = gemm_column_group(tiles_n, 256, K);
   allow_full_lds((const void*)gemm_bf16_ring_kernel<EPI>);
   hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3(groups * tiles_n * 8), dim3(512), 5 * 32768, st,
+                     (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup);
+}
+
+// grid of the persistent kernel: 8 P workgroups, P <= 32 per XCD, every XCD's stream at least P tiles long
+static int pring_cus_per_xcd(int M, int N) {
+  const int tiles_n = N / 256, mblocks = (M + GBM - 1) / GBM;
+  if (N % 256 || mblocks < 8) return 0;
+  const int n_min = (mblocks / 8) * tiles_n;                 // tiles of the XCD with the fewest row blocks
+  return n_min < 32 ? n_min : 32;
+}
+
+template <int EPI>
+static void launch_gemm_pring(const void* x, const void* w, const void* bias, void* aux, void* y, int M, int N, int K,
+                              hipStream_t st) {
+  const int tiles_n = N / 256, mblocks = (M + GBM - 1) / GBM;
+  const int ngroup = gemm_column_group(tiles_n, 256, K);
+  const int P = pring_cus_per_xcd(M, N);
+  const int grid = 8 * P;
+  allow_full_lds((const void*)gemm_bf16_pring_kernel<EPI>);
+  hipLaunchKernelGGL((gemm_bf16_pring_kernel<EPI>), dim3(grid), dim3(512), 5 * 32768, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
                      (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup);
 }
@@ -446,6 +759,14 @@ static int gemm_dispatch(const void* x, const void* w, const void* bias, void* a
     const double eff = tiles / (rounds * 256.0) * (bn == 256 ? 1.0 : bn == 192 ? 0.8 : 0.6);   // measured: the narrow
                                                        // two-stage tiles run at 0.6 - 0.8 of the ring kernel's rate
     if (eff > best_eff + 1e-9) { best_eff = eff; best_bn = bn; }
+  }
+  // the persistent kernel where every XCD has at least one tile per CU of a full grid and K >= 3 steps (measured on one
+  // MI355X, M = 50 432: fc1 + GELU 288 vs 327 us, fc2 220 vs 237, qkv 181 vs 207, proj 68 vs 76, student fc1 51 vs 66)
+  if (pring_cus_per_xcd(m, N) == 32 && K >= 192) {
+#define BASD_PRING(E) launch_gemm_pring<E>(x, w, bias, aux, y, m, N, K, st)
+    BASD_GEMM_EPI(BASD_PRING);
+#undef BASD_PRING
+    return check_launch(what);
   }
 #define BASD_RING(E) launch_gemm_ring<E>(x, w, bias, aux, y, m, N, K, st)
 #define BASD_NT192(E) launch_gemm<192, E>(x, w, bias, aux, y, m, N, K, st)
