@@ -207,19 +207,23 @@ int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int tr
  * call sites src/models/teacher.py:212 and src/training/trainer.py:33; with w := W^T also the input gradient
  * dX = dY W of trainer.py:157):   y[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]),
  * x [M, K], w [N, K], y [M, N], bias [N] (nullable) all bf16 row-major, fp32 accumulation.
- * epilogue: 0 = none, 1 = + bias, 2 = exact-erf GELU(+ bias).  K % 64 == 0, N a multiple of 256, 192 or 128. */
+ * epilogue: 0 = none, 1 = + bias, 2 = exact-erf GELU(+ bias).  K % 64 == 0, N a multiple of 256, 192 or 128.
+ * tile_run: how many output tiles a workgroup of the persistent kernel (large M, N % 256 == 0, K >= 192) multiplies
+ * before it retires: 0 = its whole share (one workgroup per CU for the whole launch: fastest when the GEMM has the GPU
+ * to itself), k >= 1 = at most k (the CUs come free every k tiles: for launches that share the GPU with another
+ * stream; the pipelined BASD step uses 2).  The results do not depend on it. */
 int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
-                   int epilogue, void* stream);
+                   int epilogue, int tile_run, void* stream);
 
 /* The trained student's MLP (timm Mlp: fc1 -> nn.GELU -> fc2, trainer.py:33 / :157) without a separate GELU pass:
  *   fwd:  pre[m][n] = bf16(sum_k x[m][k] w[n][k] + bias[n])   (saved for backward),   y = bf16(gelu(pre))
  *   bwd:  dpre[m][n] = bf16((sum_k dy[m][k] wt[n][k]) * gelu'(pre[m][n]))   with wt = fc2.weight^T  [N = hidden, K = out]
  * exact-erf GELU and its derivative Phi(x) + x phi(x), evaluated in fp32 on the bf16-rounded pre-activation (what
- * nn.GELU and its autograd see behind a bf16 nn.Linear).  Shapes as basd_gemm_bf16. */
+ * nn.GELU and its autograd see behind a bf16 nn.Linear).  Shapes and tile_run as basd_gemm_bf16. */
 int basd_gemm_bf16_gelu_fwd(const void* x, const void* w, const void* bias, void* pre, void* y, int64_t M, int N,
-                            int K, void* stream);
+                            int K, int tile_run, void* stream);
 int basd_gemm_bf16_gelu_bwd(const void* dy, const void* wt, const void* pre, void* dpre, int64_t M, int N, int K,
-                            void* stream);
+                            int tile_run, void* stream);
 
 /* ViT weight-gradient GEMM (backward of nn.Linear): dw[n][k] += sum_m dy[m][n] x[m][k],
  * db[n] += sum_m dy[m][n] (db may be NULL).  dy [M, N], x [M, K] bf16 row-major, dw [N, K] /

@@ -51,9 +51,9 @@ _SIGNATURES = {
     "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
     "basd_wgrad_workspace_bytes": (_I64, _I, _I),
     "basd_wgrad_bf16_ws": (_P, _P, _I64, _I, _I, _P, _P, _P, _I64, _P),
-    "basd_gemm_bf16": (_P, _P, _P, _P, _I64, _I, _I, _I, _P),
-    "basd_gemm_bf16_gelu_fwd": (_P, _P, _P, _P, _P, _I64, _I, _I, _P),
-    "basd_gemm_bf16_gelu_bwd": (_P, _P, _P, _P, _I64, _I, _I, _P),
+    "basd_gemm_bf16": (_P, _P, _P, _P, _I64, _I, _I, _I, _I, _P),
+    "basd_gemm_bf16_gelu_fwd": (_P, _P, _P, _P, _P, _I64, _I, _I, _I, _P),
+    "basd_gemm_bf16_gelu_bwd": (_P, _P, _P, _P, _I64, _I, _I, _I, _P),
     "basd_layernorm_fwd_bf16": (_P, _P, _P, _I64, _I, _F, _P, _P, _P, _P),
     "basd_add_layernorm_fwd_bf16": (_P, _P, _P, _P, _I64, _I, _F, _P, _P, _P, _P, _P, _I, _P),
     "basd_layernorm_bwd_bf16": (_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _I, _P),
@@ -568,6 +568,13 @@ def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor) -> torch.T
     return out
 
 
+# Tiles a workgroup of the persistent GEMM kernel multiplies before it retires (basd_gemm_bf16's ``tile_run``): 0 = its
+# whole share, the fastest form when the GEMM has the GPU to itself (the default: inference, eager / single-stream steps);
+# the Trainer sets 2 while its two-stream pipelined step is in use (a persistent launch holds every CU until it ends and
+# the other stream's short kernels queue behind it: measured 41.3 vs 39.5 ms per c2 step).
+GEMM_TILE_RUN = 0
+
+
 def gemm_supported(n: int, k: int) -> bool:
     return k % 64 == 0 and k >= 64 and n >= 128 and (n % 256 == 0 or n % 192 == 0 or n % 128 == 0)
 
@@ -587,7 +594,7 @@ def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None
     y = torch.empty(x2.shape[0], n, dtype=torch.bfloat16, device=x.device)
     epi = 2 if gelu else (1 if bias is not None else 0)
     _check(lib().basd_gemm_bf16(_ptr(x2), _ptr(w), _ptr(None if bias is None else bias.contiguous()), _ptr(y),
-                                ctypes.c_int64(x2.shape[0]), n, k, epi, _stream()), "basd_gemm_bf16")
+                                ctypes.c_int64(x2.shape[0]), n, k, epi, GEMM_TILE_RUN, _stream()), "basd_gemm_bf16")
     return y.view(*x.shape[:-1], n)
 
 
@@ -604,7 +611,8 @@ def gemm_gelu_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None):
     pre = torch.empty(x2.shape[0], n, dtype=torch.bfloat16, device=x.device)
     act = torch.empty_like(pre)
     _check(lib().basd_gemm_bf16_gelu_fwd(_ptr(x2), _ptr(w.contiguous()), _ptr(None if bias is None else bias.contiguous()),
-                                         _ptr(pre), _ptr(act), ctypes.c_int64(x2.shape[0]), n, k, _stream()),
+                                         _ptr(pre), _ptr(act), ctypes.c_int64(x2.shape[0]), n, k, GEMM_TILE_RUN,
+                                         _stream()),
            "basd_gemm_bf16_gelu_fwd")
     return pre.view(*x.shape[:-1], n), act.view(*x.shape[:-1], n)
 
@@ -623,7 +631,8 @@ def gemm_gelu_bwd(dy: torch.Tensor, wt: torch.Tensor, pre: torch.Tensor) -> torc
     assert pre2.is_contiguous() and pre2.shape[0] == dy2.shape[0]
     out = torch.empty_like(pre2)
     _check(lib().basd_gemm_bf16_gelu_bwd(_ptr(dy2), _ptr(wt.contiguous()), _ptr(pre2), _ptr(out),
-                                         ctypes.c_int64(dy2.shape[0]), n, k, _stream()), "basd_gemm_bf16_gelu_bwd")
+                                         ctypes.c_int64(dy2.shape[0]), n, k, GEMM_TILE_RUN, _stream()),
+           "basd_gemm_bf16_gelu_bwd")
     return out.view(*pre.shape)
 
 

@@ -489,7 +489,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ W,
                                                               const unsigned short* __restrict__ bias,
                                                               unsigned short* aux, unsigned short* __restrict__ Y,
-                                                              int M, int N, int K, int tiles_n, int mblocks, int ngroup) {
+                                                              int M, int N, int K, int tiles_n, int mblocks, int ngroup,
+                                                              int chunk_tiles) {
   extern __shared__ __align__(16) unsigned char g_lds[];
   constexpr int NT = 4, UNIT = 32768, NSLOT = 5;
   constexpr int NST = (EPI == 3) ? 32 : 16;                 // global stores of a wave per epilogue
@@ -499,7 +500,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
   const int nk = K / GBK;                                   // >= 3 (launcher)
 
   // ---- this workgroup's range of the XCD's stream
-  const int xcd = blockIdx.x & 7, ci = blockIdx.x >> 3, P = gridDim.x >> 3;
+  // grid = chunks x 8 P: workgroup (chunk c, XCD x, rank i) walks the tiles [c T, (c + 1) T) of block i (T = chunk_tiles;
+  // one chunk = fully persistent).  Chunks are dispatched in order as CUs come free.
+  const int P = 32;
+  const int chunk = blockIdx.x / (8 * P), slot_id = blockIdx.x - chunk * (8 * P);
+  const int xcd = slot_id & 7, ci = slot_id >> 3;
   const int rb = (mblocks - xcd + 7) >> 3;                  // >= 1 (launcher: mblocks >= 8)
   const int n_x = rb * tiles_n, R0 = n_x / P, rem = n_x - R0 * P;
   auto block_pos = [&](int b) { return b * R0 + (b * rem + P - 1) / P; };      // position of block b's first tile
@@ -510,8 +515,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
     m0_ = (mbl * 8 + xcd) * GBM;
     n0_ = (ng * ngroup + nbi) * 256;
   };
-  const int ntiles = block_pos(ci + 1) - block_pos(ci);     // R0 or R0 + 1 (>= 1: launcher)
-  int o = 0;                                                // tile of the block being multiplied
+  const int block_tiles = block_pos(ci + 1) - block_pos(ci);   // R0 or R0 + 1 (>= 1: launcher)
+  int o = chunk * chunk_tiles;                              // tile of the block being multiplied
+  const int ntiles = o + chunk_tiles < block_tiles ? o + chunk_tiles : block_tiles;
+  if (o >= ntiles) return;
 
   // ---- per-lane byte offsets of the LDS-DMA pieces inside a tile's operand panel (row pitch K): piece j of a unit
   //      is sub-tile s = wave + 8 j: row block s >> 1, k block s & 1
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
 
   // ---- first segment
   int m0, n0;
-  tile_at(0, m0, n0);
+  tile_at(o, m0, n0);
   const unsigned char* a_cur = reinterpret_cast<const unsigned char*>(X) + (size_t)m0 * K * 2;
   const unsigned char* b_cur = reinterpret_cast<const unsigned char*>(W) + (size_t)n0 * K * 2;
   set_off_a(m0);
@@ -701,15 +708,17 @@ static int pring_cus_per_xcd(int M, int N) {
 
 template <int EPI>
 static void launch_gemm_pring(const void* x, const void* w, const void* bias, void* aux, void* y, int M, int N, int K,
-                              hipStream_t st) {
+                              int tile_run, hipStream_t st) {
   const int tiles_n = N / 256, mblocks = (M + GBM - 1) / GBM;
   const int ngroup = gemm_column_group(tiles_n, 256, K);
-  const int P = pring_cus_per_xcd(M, N);
-  const int grid = 8 * P;
+  const int chunk_tiles = tile_run > 0 ? tile_run : 1 << 20;
+  const int max_block = ((mblocks + 7) / 8 * tiles_n + 31) / 32;
+  const int chunks = (max_block + chunk_tiles - 1) / chunk_tiles;
+  const int grid = 8 * 32 * chunks;
   allow_full_lds((const void*)gemm_bf16_pring_kernel<EPI>);
   hipLaunchKernelGGL((gemm_bf16_pring_kernel<EPI>), dim3(grid), dim3(512), 5 * 32768, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
-                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup);
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup, chunk_tiles);
 }
 
 template <int BN, int EPI>
@@ -728,7 +737,7 @@ static void launch_gemm(const void* x, const void* w, const void* bias, void* au
 }  // namespace basd
 
 static int gemm_dispatch(const void* x, const void* w, const void* bias, void* aux, void* y, int64_t M, int N, int K,
-                         int epilogue, void* stream, const char* what) {
+                         int epilogue, int tile_run, void* stream, const char* what) {
   using namespace basd;
   if (M <= 0) return BASD_OK;
   if (M > 0x7fffff00LL) return fail(BASD_ERR_SHAPE, "%s: M = %lld too large", what, (long long)M);
@@ -763,7 +772,7 @@ static int gemm_dispatch(const void* x, const void* w, const void* bias, void* a
   // the persistent kernel where every XCD has at least one tile per CU of a full grid and K >= 3 steps (measured on one
   // MI355X, M = 50 432: fc1 + GELU 288 vs 327 us, fc2 220 vs 237, qkv 181 vs 207, proj 68 vs 76, student fc1 51 vs 66)
   if (pring_cus_per_xcd(m, N) == 32 && K >= 192) {
-#define BASD_PRING(E) launch_gemm_pring<E>(x, w, bias, aux, y, m, N, K, st)
+#define BASD_PRING(E) launch_gemm_pring<E>(x, w, bias, aux, y, m, N, K, tile_run, st)
     BASD_GEMM_EPI(BASD_PRING);
 #undef BASD_PRING
     return check_launch(what);
@@ -782,24 +791,24 @@ static int gemm_dispatch(const void* x, const void* w, const void* bias, void* a
 }
 
 extern "C" int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
-                              int epilogue, void* stream) {
+                              int epilogue, int tile_run, void* stream) {
   using namespace basd;
   if (epilogue < 0 || epilogue > 2) return fail(BASD_ERR_SHAPE, "gemm_bf16: epilogue %d not in {0, 1, 2}", epilogue);
   if (epilogue == 1 && bias == nullptr) epilogue = 0;
-  return gemm_dispatch(x, w, bias, nullptr, y, M, N, K, epilogue, stream, "gemm_bf16");
+  return gemm_dispatch(x, w, bias, nullptr, y, M, N, K, epilogue, tile_run, stream, "gemm_bf16");
 }
 
 extern "C" int basd_gemm_bf16_gelu_fwd(const void* x, const void* w, const void* bias, void* pre, void* y, int64_t M,
-                                       int N, int K, void* stream) {
+                                       int N, int K, int tile_run, void* stream) {
   using namespace basd;
   if (M > 0 && (pre == nullptr || y == nullptr)) return fail(BASD_ERR_SHAPE, "gemm_bf16_gelu_fwd: pre and y are required");
-  return gemm_dispatch(x, w, bias, pre, y, M, N, K, 3, stream, "gemm_bf16_gelu_fwd");
+  return gemm_dispatch(x, w, bias, pre, y, M, N, K, 3, tile_run, stream, "gemm_bf16_gelu_fwd");
 }
 
 extern "C" int basd_gemm_bf16_gelu_bwd(const void* dy, const void* wt, const void* pre, void* dpre, int64_t M, int N,
-                                       int K, void* stream) {
+                                       int K, int tile_run, void* stream) {
   using namespace basd;
   if (M > 0 && (pre == nullptr || dpre == nullptr))
     return fail(BASD_ERR_SHAPE, "gemm_bf16_gelu_bwd: pre and dpre are required");
-  return gemm_dispatch(dy, wt, nullptr, const_cast<void*>(pre), dpre, M, N, K, 4, stream, "gemm_bf16_gelu_bwd");
+  return gemm_dispatch(dy, wt, nullptr, const_cast<void*>(pre), dpre, M, N, K, 4, tile_run, stream, "gemm_bf16_gelu_bwd");
 }

@@ -106,6 +106,13 @@ class Trainer:
         self.pipeline_teacher = str(config.basd.get("pipeline_teacher", "true")).lower() in ("1", "true")
         self._pipe = None
         self.pipeline_error = None
+        # The step runs two streams (teacher branch / student + loss).  A fully persistent GEMM launch holds every CU until
+        # it ends, and the other stream's short kernels queue behind it (c2, same box: 41.3 ms per step against 39.5 with
+        # workgroups that retire every two tiles; alone on the GPU the persistent form is the fastest: fc1 + GELU 288 vs
+        # 327 us).  basd.gemm_tile_run overrides (0 = fully persistent).
+        if self.device.type == "cuda":
+            from .. import _native
+            _native.GEMM_TILE_RUN = int(config.basd.get("gemm_tile_run", 2))
         self._graph_pool = None
         self._side = None
         self._graph = None
