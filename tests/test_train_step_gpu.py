@@ -245,3 +245,69 @@ def test_fused_teacher_blocks_match_library_path(monkeypatch):
         assert rel < 1.5e-2, (j, rel)
         assert torch.allclose(imp_f[j], imp_l[j], rtol=5e-2, atol=2e-5), j
         assert abs(float(imp_f[j].sum(-1).mean()) - float(imp_l[j].sum(-1).mean())) < 1e-3
+
+
+def test_vit_huge_teacher_stays_on_the_hip_path_in_strict_mode():
+    """BASELINE configs[4]'s teacher (ViT-H/14: head dim 80, 257 tokens, 588-value patches): with strict mode on, a
+    library fallback in any block would raise; the fused attention tap must agree with the reference-style hook
+    (softmax(QK^T / sqrt(hd)) rebuilt from qkv, src/models/teacher.py:27-39) on the same activations."""
+    import basd_amd.losses._ops as O
+    from basd_amd.models.teacher import extract_intermediates, load_teacher
+    teacher = load_teacher("vit_huge_patch14_224", 224, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    O.FALLBACKS.clear()
+    O.set_strict(True)
+    try:
+        with torch.no_grad():
+            toks, imps = extract_intermediates(teacher, x)
+    finally:
+        O.set_strict(False)
+    assert not O.FALLBACKS, dict(O.FALLBACKS)
+    assert len(toks) == 32 and toks[0].shape == (2, 256, 1280) and imps[31].shape == (2, 256)
+    for j in (0, 31):
+        assert bool(torch.isfinite(toks[j].float()).all())
+        assert torch.allclose(imps[j].sum(-1), torch.full((2,), float(imps[j].sum(-1)[0]), device="cuda"), atol=0.5)
+    # the tap against the hook formulation on block 0's own input
+    blk = teacher.model.blocks[0]
+    with torch.no_grad():
+        h = teacher.model.patch_embed(x.to(torch.bfloat16))
+        h = torch.cat([teacher.model.cls_token.expand(2, -1, -1), h], dim=1) + teacher.model.pos_embed
+        qkv = blk.attn.qkv(blk.norm1(h)).reshape(2, 257, 3, 16, 80).permute(2, 0, 3, 1, 4)
+        q, k = qkv[0].float(), qkv[1].float()
+        logits = (q[:, :, :1] @ k.transpose(-2, -1)).to(torch.bfloat16).float() * 80 ** -0.5
+        want = logits.softmax(dim=-1)[:, :, 0, 1:].mean(dim=1)
+    assert torch.allclose(imps[0], want, rtol=5e-2, atol=2e-5)
+
+
+def _make_preset(student, teacher, batch, img=224, patch=16):
+    from basd_amd.config import load_config
+    from basd_amd.train import SyntheticLoader, build
+    torch.manual_seed(0)
+    cfg = load_config(CFG, None, [f"data.batch_size={batch}", "data.dataset=synthetic", f"model.student_preset={student}",
+                                  f"basd.teacher_model_name={teacher}", f"model.vit.img_size={img}",
+                                  f"model.vit.patch_size={patch}", "model.drop_path_rate=0.0"])
+    trainer, _ = build(cfg, device="cuda")
+    trainer.use_mixup = False
+    trainer.optimizer.train()
+    trainer.model.train()
+    b = next(iter(SyntheticLoader(batch, img, cfg.model.num_classes, 1, "cuda", seed=5)))
+    return trainer, b
+
+
+@pytest.mark.parametrize("student,teacher,batch", [("deit_tiny_patch16_224", "vit_base_patch16_224", 8),
+                                                   ("vit_base_patch16_224", "vit_huge_patch14_224", 2)])
+def test_a_train_step_has_no_library_fallback_in_strict_mode(student, teacher, batch):
+    """BASELINE configs[1] and configs[4] model pairs at a small batch, BASD_STRICT semantics: no ViT block, patch
+    embedding or attention of either model leaves the hand-written kernels during a whole step (the 1000-class head is
+    the one declared library call)"""
+    import basd_amd.losses._ops as O
+    trainer, b = _make_preset(student, teacher, batch)
+    O.FALLBACKS.clear()
+    O.set_strict(True)
+    try:
+        loss, _ = trainer.train_step(b)
+        trainer.check_health()
+    finally:
+        O.set_strict(False)
+    assert float(loss) == float(loss)
+    assert not O.FALLBACKS, dict(O.FALLBACKS)

@@ -681,7 +681,7 @@ def _wgrad_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 
 
 def cls_importance_supported(t: int, hd: int) -> bool:
-    return 2 <= t <= 256 and hd in (32, 64)
+    return 2 <= t <= 320 and hd in (32, 64, 80)
 
 
 def cls_importance(qkv: torch.Tensor, heads: int, head_dim: int, scale: float) -> torch.Tensor:
@@ -697,7 +697,7 @@ def cls_importance(qkv: torch.Tensor, heads: int, head_dim: int, scale: float) -
 
 
 def attention_fwd_supported(t: int, hd: int) -> bool:
-    return hd == 64 and 1 <= t <= 272
+    return hd in (64, 80) and 1 <= t <= 272
 
 
 def attention_fwd(qkv: torch.Tensor, heads: int, head_dim: int, scale: float, want_importance: bool = False,

@@ -7,8 +7,9 @@
 // src/models/teacher.py:27-39 builds the full [B, H, T, T] map from a second qkv GEMM;
 // src/losses/relational.py:22-27 keeps the head-averaged CLS row).
 //
-// One workgroup (4 waves) per (batch, head).  T <= 272 tokens, hd = 64: K and V of the head live in LDS
-// (row-major, 144-byte rows), every wave owns 16-query tiles.
+// One workgroup (4 waves) per (batch, head).  T <= 272 tokens, hd = 64 or 80 (ViT-H/14: the contraction of Q K^T runs
+// over three 32-deep steps with d = 80..95 zero, the output over five 16-column tiles): K and V of the head live in LDS
+// (row-major, rows of hd (padded to a multiple of 32) + 8 elements), every wave owns 16-query tiles.
 //   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K rows from LDS (ds_read_b128), B = Q rows from global:
 //                 the accumulator of key tile kt holds, for query column lane & 15, the keys
 //                 16 kt + 4 (lane >> 4) + {0..3};
@@ -27,8 +28,6 @@ typedef short at_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short at_v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) at_v4s at_lds_v4s;
 
-constexpr int AT_HD = 64;
-constexpr int AT_LD = AT_HD + 8;          // LDS row stride in bf16 (144 B: 16-byte aligned, bank rotation)
 
 typedef float at_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 at_bf16x2 __attribute__((ext_vector_type(2)));
@@ -44,12 +43,17 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   return (unsigned short)(u >> 16);
 }
 
-template <int NKT>   // key tiles of 16: T <= 16 * NKT
+template <int NKT, int AT_HD>   // key tiles of 16: T <= 16 * NKT; head dim 64 or 80
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int T, int H,
                                                             float scale, unsigned short* __restrict__ out,
                                                             float* __restrict__ importance, float* __restrict__ lse) {
   constexpr int NKS = (NKT + 1) / 2;                 // 32-key steps of the P V product
   constexpr int KROWS = 32 * NKS;                    // LDS rows (zero padded)
+  constexpr int NDS = (AT_HD + 31) / 32;             // 32-deep steps of the Q K^T contraction
+  constexpr int NDT = AT_HD / 16;                    // 16-column tiles of the output
+  constexpr int NCH = AT_HD / 8;                     // 16-byte chunks of a row that hold data
+  constexpr int NCHP = NDS * 4;                      // ... of a padded row
+  constexpr int AT_LD = NDS * 32 + 8;                // LDS row stride in bf16 (16-byte aligned, bank rotation)
   extern __shared__ __align__(16) unsigned short sm[];
   unsigned short* Ks = sm;                           // [KROWS][AT_LD]
   unsigned short* Vs = Ks + KROWS * AT_LD;           // [KROWS][AT_LD]
@@ -63,15 +67,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- stage K and V of this head (16-byte chunks; rows >= T are zero).  All loads are issued before the
   //      first LDS store: a load-store-per-iteration loop exposes one HBM round trip per iteration (7 of
   //      them: 14 us of a 24 us workgroup in the first version of this kernel).
-  constexpr int NLD = (KROWS * 8 + 255) / 256;
+  constexpr int NLD = (KROWS * NCHP + 255) / 256;
   uint4 kreg[NLD], vreg[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int idx = tid + 256 * i;
-    const int r = idx >> 3, c8 = idx & 7;
+    const int r = idx / NCHP, c8 = idx - r * NCHP;
     kreg[i] = make_uint4(0, 0, 0, 0);
     vreg[i] = make_uint4(0, 0, 0, 0);
-    if (r < T) {
+    if (r < T && c8 < NCH) {
       const unsigned short* p = base + (size_t)r * row + c8 * 8;
       kreg[i] = *reinterpret_cast<const uint4*>(p + (size_t)H * AT_HD);
       vreg[i] = *reinterpret_cast<const uint4*>(p + (size_t)2 * H * AT_HD);
@@ -80,8 +84,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int idx = tid + 256 * i;
-    const int r = idx >> 3, c8 = idx & 7;
-    if (idx < KROWS * 8) {
+    const int r = idx / NCHP, c8 = idx - r * NCHP;
+    if (idx < KROWS * NCHP) {
       *reinterpret_cast<uint4*>(Ks + r * AT_LD + c8 * 8) = kreg[i];
       *reinterpret_cast<uint4*>(Vs + r * AT_LD + c8 * 8) = vreg[i];
     }
@@ -92,22 +96,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nqt = (T + 15) >> 4;
   const int full_tiles = T >> 4;                     // key tiles without padding
   unsigned short* Ow = Os + wave * 16 * AT_LD;
-  auto load_q = [&](int qt_, uint4 (&dst)[2]) {
+  auto load_q = [&](int qt_, uint4 (&dst)[NDS]) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < NDS; ++ks) {
       dst[ks] = make_uint4(0, 0, 0, 0);
-      if (qt_ < nqt && qt_ * 16 + li < T)
+      if (qt_ < nqt && qt_ * 16 + li < T && 32 * ks + 8 * g < AT_HD)
         dst[ks] = *reinterpret_cast<const uint4*>(base + (size_t)(qt_ * 16 + li) * row + 32 * ks + 8 * g);
     }
   };
-  uint4 qnext[2];
+  uint4 qnext[NDS];
   load_q(wave, qnext);
   for (int qt = wave; qt < nqt; qt += 4) {
     const int q0 = qt * 16;
     // Q fragments of this tile: query q0 + li, d = 32 ks + 8 g .. + 7 (fetched one tile ahead)
-    at_bf16x8 qf[2];
-    qf[0] = *reinterpret_cast<at_bf16x8*>(&qnext[0]);
-    qf[1] = *reinterpret_cast<at_bf16x8*>(&qnext[1]);
+    at_bf16x8 qf[NDS];
+#pragma unroll
+    for (int ks = 0; ks < NDS; ++ks) qf[ks] = *reinterpret_cast<at_bf16x8*>(&qnext[ks]);
     load_q(qt + 4, qnext);
     // ---- S^T tiles
     at_f32x4 s[NKT];
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int kt = 0; kt < NKT; ++kt) {
       at_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < NDS; ++ks) {
         const uint4 kk = *reinterpret_cast<const uint4*>(Ks + (16 * kt + li) * AT_LD + 32 * ks + 8 * g);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const at_bf16x8*>(&kk), qf[ks], acc, 0, 0, 0);
       }
@@ -189,9 +193,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // log-sum-exp of the scaled logits (natural log): what the backward kernel recomputes P from
     if (lse != nullptr && g == 0 && q0 + li < T) lse[((size_t)b * H + h) * T + q0 + li] = fmaf(mx, scale, __logf(sum));
     // ---- O = P V
-    at_f32x4 o[4];
+    at_f32x4 o[NDT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (at_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < NDT; ++dt) o[dt] = (at_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int K1 = (2 * ks + 1 < NKT) ? 2 * ks + 1 : 0;      // constant after unrolling
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // B fragment: column d = 16 dt + li, keys {32 ks + 4 g + e} and {32 ks + 16 + 4 g + e}, e = 0..3
       const int qq = li >> 2, pp = li & 3;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < NDT; ++dt) {
         const unsigned short* a0 = Vs + (32 * ks + 4 * g + qq) * AT_LD + 16 * dt + 4 * pp;
         const at_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s*)a0);
         const at_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s*)(a0 + 16 * AT_LD));
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // ---- o[dt][r] = O[query q0 + 4 g + r][d = 16 dt + li]: through LDS, then 16-byte row stores
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
         const unsigned int w = pack_bf16(o[dt][r], o[dt][r + 1]);
@@ -224,9 +228,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the tile is private to this wave: LDS operations of a wave complete in order
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int idx = lane + 64 * c, r = idx >> 3, c8 = idx & 7;
-      if (q0 + r < T) {
+    for (int c = 0; c < (16 * NCH + 63) / 64; ++c) {
+      const int idx = lane + 64 * c, r = idx / NCH, c8 = idx - r * NCH;
+      if (idx < 16 * NCH && q0 + r < T) {
         const uint4 v = *reinterpret_cast<const uint4*>(Ow + r * AT_LD + c8 * 8);
         *reinterpret_cast<uint4*>(out + ((size_t)(b * T + q0 + r) * H + h) * AT_HD + c8 * 8) = v;
       }
@@ -235,14 +239,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int NKT>
+template <int NKT, int HD>
 static void launch_attention(const void* qkv, int B, int T, int H, float scale, void* out, float* importance,
                              float* lse, hipStream_t st) {
   constexpr int KROWS = 32 * ((NKT + 1) / 2);
-  const size_t lds = ((size_t)2 * KROWS * AT_LD + 4 * 16 * AT_LD) * sizeof(unsigned short);
-  allow_full_lds((const void*)attention_fwd_kernel<NKT>);
-  hipLaunchKernelGGL(attention_fwd_kernel<NKT>, dim3(B * H), dim3(256), lds, st, (const unsigned short*)qkv, T, H, scale,
-                     (unsigned short*)out, importance, lse);
+  constexpr int LD = (HD + 31) / 32 * 32 + 8;
+  const size_t lds = ((size_t)2 * KROWS * LD + 4 * 16 * LD) * sizeof(unsigned short);
+  allow_full_lds((const void*)attention_fwd_kernel<NKT, HD>);
+  hipLaunchKernelGGL((attention_fwd_kernel<NKT, HD>), dim3(B * H), dim3(256), lds, st, (const unsigned short*)qkv, T, H,
+                     scale, (unsigned short*)out, importance, lse);
 }
 
 }  // namespace basd
@@ -251,12 +256,17 @@ extern "C" int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int
                                        float* importance, float* lse, void* stream) {
   using namespace basd;
   if (B <= 0) return BASD_OK;
-  if (hd != AT_HD || T < 1 || T > 272 || H < 1)
-    return fail(BASD_ERR_SHAPE, "attention_fwd: T=%d H=%d hd=%d unsupported (hd 64, T <= 272)", T, H, hd);
+  if ((hd != 64 && hd != 80) || T < 1 || T > 272 || H < 1)
+    return fail(BASD_ERR_SHAPE, "attention_fwd: T=%d H=%d hd=%d unsupported (hd 64 | 80, T <= 272)", T, H, hd);
   if (importance != nullptr && T < 2) return fail(BASD_ERR_SHAPE, "attention_fwd: importance needs T >= 2");
   hipStream_t st = (hipStream_t)stream;
-  if (T <= 64) launch_attention<4>(qkv, B, T, H, scale, out, importance, lse, st);
-  else if (T <= 208) launch_attention<13>(qkv, B, T, H, scale, out, importance, lse, st);
-  else launch_attention<17>(qkv, B, T, H, scale, out, importance, lse, st);
+  if (hd == 64) {
+    if (T <= 64) launch_attention<4, 64>(qkv, B, T, H, scale, out, importance, lse, st);
+    else if (T <= 208) launch_attention<13, 64>(qkv, B, T, H, scale, out, importance, lse, st);
+    else launch_attention<17, 64>(qkv, B, T, H, scale, out, importance, lse, st);
+  } else {
+    if (T <= 208) launch_attention<13, 80>(qkv, B, T, H, scale, out, importance, lse, st);
+    else launch_attention<17, 80>(qkv, B, T, H, scale, out, importance, lse, st);
+  }
   return check_launch("attention_fwd");
 }

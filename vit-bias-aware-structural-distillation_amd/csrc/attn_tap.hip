@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void cls_importance_kernel(const unsigned shor
   const unsigned short* base = qkv + (size_t)blockIdx.x * T * row;
   float* acc = s_acc + (size_t)wave * T;
   for (int t = lane; t < T; t += 64) acc[t] = 0.f;
-  constexpr int MAXT = 4;                          // tokens per lane: T <= 256
+  constexpr int MAXT = 5;                          // tokens per lane: T <= 320
   for (int h = wave; h < H; h += nw) {
     // q of the CLS token, this head (same for every lane: scalar loads)
     float q[HD];
@@ -87,12 +87,14 @@ extern "C" int basd_cls_importance_bf16(const void* qkv, int B, int T, int H, in
                                         void* stream) {
   using namespace basd;
   if (B <= 0) return BASD_OK;
-  if (T < 2 || T > 256 || H < 1 || (hd != 32 && hd != 64))
-    return fail(BASD_ERR_SHAPE, "cls_importance: T=%d H=%d hd=%d unsupported (2 <= T <= 256, hd 32|64)", T, H, hd);
+  if (T < 2 || T > 320 || H < 1 || (hd != 32 && hd != 64 && hd != 80))
+    return fail(BASD_ERR_SHAPE, "cls_importance: T=%d H=%d hd=%d unsupported (2 <= T <= 320, hd 32|64|80)", T, H, hd);
   const size_t lds = (size_t)4 * T * sizeof(float);
   const unsigned short* p = (const unsigned short*)qkv;
   if (hd == 64)
     hipLaunchKernelGGL(cls_importance_kernel<64>, dim3(B), dim3(256), lds, (hipStream_t)stream, p, T, H, scale, out);
+  else if (hd == 80)
+    hipLaunchKernelGGL(cls_importance_kernel<80>, dim3(B), dim3(256), lds, (hipStream_t)stream, p, T, H, scale, out);
   else
     hipLaunchKernelGGL(cls_importance_kernel<32>, dim3(B), dim3(256), lds, (hipStream_t)stream, p, T, H, scale, out);
   return check_launch("cls_importance");

@@ -26,3 +26,32 @@ def set_ops(provider) -> None:
     """Tests only."""
     global _ops
     _ops = provider
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Strict mode.  A layer whose shape the hand-written kernels do not tile falls back to a library kernel (hipBLASLt /
+# aten): correct, but not the path BASELINE.json's north_star asks for, and silent.  Every such fallback on DEVICE
+# tensors goes through ``library_fallback``: it is counted (``FALLBACKS``, reported by bench.py) and, with BASD_STRICT=1
+# in the environment (or ``set_strict(True)``), it raises instead.  Layers that are declared library calls (the
+# 1000-class head: N = 1000 on 256 CLS rows, 0.05 ms) carry ``library_ok = True`` and do not count.
+import collections
+import os
+
+STRICT = os.environ.get("BASD_STRICT", "0") == "1"
+FALLBACKS: "collections.Counter[str]" = collections.Counter()
+
+
+class StrictModeError(RuntimeError):
+    pass
+
+
+def set_strict(on: bool) -> None:
+    global STRICT
+    STRICT = bool(on)
+
+
+def library_fallback(what: str, detail: str = "") -> None:
+    """Call right before running a library kernel in place of a hand-written one (device tensors only)."""
+    FALLBACKS[what] += 1
+    if STRICT:
+        raise StrictModeError(f"BASD_STRICT: {what} would run on a library kernel instead of the HIP path ({detail})")

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..losses._ops import get_ops
+from ..losses._ops import get_ops, library_fallback
 
 
 def _bf16_of(p):
@@ -22,6 +22,14 @@ def _bf16_of(p):
         return None
     p16 = getattr(p, "_basd_bf16", None)
     return p16 if p16 is not None else p.to(torch.bfloat16)
+
+
+def _bf16_compute(x) -> bool:
+    """bf16 activations, or bf16 autocast on the device of ``x``"""
+    if x.dtype == torch.bfloat16:
+        return True
+    dev = x.device.type
+    return torch.is_autocast_enabled(dev) and torch.get_autocast_dtype(dev) == torch.bfloat16
 
 
 def _bf16_transposed(weight, w16):
@@ -58,6 +66,7 @@ class _LinearFn(torch.autograd.Function):
         ops = get_ops()
         if ops.gemm_supported(w16.shape[0], w16.shape[1]):
             return ops.gemm_bf16(x16, w16, b16)             # hand-written MFMA GEMM, bias in the epilogue
+        library_fallback("linear forward", f"N={w16.shape[0]} K={w16.shape[1]}")
         return F.linear(x16, w16, b16)
 
     @staticmethod
@@ -72,6 +81,7 @@ class _LinearFn(torch.autograd.Function):
                 # dX = dY W as the same "NT" kernel on the transposed weight (<= 0.6 M elements: the copy is noise)
                 gx = ops.gemm_bf16(g16, _bf16_transposed(weight, w16)).to(ctx.x_dtype)
             else:
+                library_fallback("linear input gradient", f"N={w16.shape[1]} K={w16.shape[0]}")
                 gx = (g16 @ w16).to(ctx.x_dtype)
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
             gw, gb = _weight_grads(weight, bias, g16.reshape(-1, g16.shape[-1]), x16.reshape(-1, x16.shape[-1]))
@@ -143,6 +153,15 @@ class BasdLinear(nn.Linear):
                 return _LinearFn.apply(x, self.weight, self.bias)
         if self.fused_inference_ok(x):
             return get_ops().gemm_bf16(x, self.weight, self.bias)
+        if (get_ops().handles(x) and not torch.is_grad_enabled() and x.dim() >= 2
+                and get_ops().gemm_supported(self.out_features, self.in_features) and _bf16_compute(x)):
+            # evaluation of a TRAINED layer (fp32 master weights under bf16 autocast): same kernel, weights cast per
+            # call (the optimizer's eval / train switch moves the weights, the step's bf16 images may be stale here)
+            return get_ops().gemm_bf16(x.to(torch.bfloat16), self.weight.to(torch.bfloat16),
+                                       None if self.bias is None else self.bias.to(torch.bfloat16))
+        if get_ops().handles(x) and not getattr(self, "library_ok", False):
+            library_fallback("linear", f"{self.in_features}->{self.out_features} dtype={x.dtype} rows="
+                                       f"{x.numel() // max(1, x.shape[-1])} grad={torch.is_grad_enabled()}")
         return F.linear(x, self.weight, self.bias)
 
     def fused_inference_ok(self, x) -> bool:

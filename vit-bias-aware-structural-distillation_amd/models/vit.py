@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
-from ..losses._ops import get_ops
+from ..losses._ops import get_ops, library_fallback
 from .linear import BasdLinear, _LinearFn, fused_mlp, fused_mlp_ok
 
 
@@ -248,14 +248,20 @@ class Attention(nn.Module):
             return self.proj(_FusedAttention.apply(qkv_flat.contiguous(), self.num_heads, self.head_dim, self.scale))
         qkv = qkv_flat.reshape(b, t, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
+        on_device = get_ops().handles(qkv_flat)
         if self.tap is not None:
-            ops = get_ops() if get_ops().handles(qkv_flat) else None
+            ops = get_ops() if on_device else None
             if (ops is not None and self.tap["has_cls"] and qkv_flat.dtype == torch.bfloat16
                     and ops.cls_importance_supported(t, self.head_dim)):
                 # fused tap: streams K once from the packed projection (csrc/attn_tap.hip)
                 self.tap["out"] = ops.cls_importance(qkv_flat, self.num_heads, self.head_dim, self.scale)
             else:
+                if on_device and self.tap["has_cls"]:
+                    library_fallback("attention tap", f"T={t} head_dim={self.head_dim} dtype={qkv_flat.dtype}")
                 self.tap["out"] = self._importance(q, k, self.tap["has_cls"])
+        if on_device:
+            library_fallback("attention", f"T={t} head_dim={self.head_dim} dtype={qkv_flat.dtype} "
+                                          f"grad={torch.is_grad_enabled() and qkv_flat.requires_grad}")
         global _packed_attention_ok
         out = None
         if (_packed_attention_ok and qkv_flat.is_cuda and qkv_flat.dtype in (torch.bfloat16, torch.float16)
@@ -292,6 +298,8 @@ class Mlp(nn.Module):
             return self.fc2(get_ops().gemm_bf16(x, self.fc1.weight, self.fc1.bias, gelu=True))
         if fused_mlp_ok(x, self.fc1, self.fc2):   # trained block: GELU forward / backward inside the GEMM epilogues
             return fused_mlp(x, self.fc1, self.fc2)
+        if get_ops().handles(x):
+            library_fallback("MLP GELU", f"fc1 {self.fc1.in_features}->{self.fc1.out_features} dtype={x.dtype}")
         return self.fc2(self.act(self.fc1(x)))
 
 
@@ -379,7 +387,24 @@ class PatchEmbed(nn.Module):
                     return _LinearFn.apply(patches, w2, self.proj.bias)
             if not torch.is_grad_enabled() and w2.dtype == torch.bfloat16 and self.proj.bias.dtype == torch.bfloat16:
                 return ops.gemm_bf16(patches, w2, self.proj.bias)
+            library_fallback("patch embedding", f"K={k} D={d}: bf16 compute of fp32 frozen weights")
             return F.linear(patches, w2.to(torch.bfloat16), self.proj.bias.to(torch.bfloat16))
+        k_pad = (k + 63) // 64 * 64
+        if (ops.handles(x) and not torch.is_grad_enabled() and self.proj.weight.dtype == torch.bfloat16
+                and self.proj.bias is not None and self.proj.bias.dtype == torch.bfloat16 and ops.gemm_supported(d, k_pad)):
+            # frozen bf16 layer whose patch is not a multiple of 64 values (ViT-H/14: 3 x 14 x 14 = 588): K padded with
+            # zero columns on both operands (the padded weight is kept: the layer is frozen)
+            patches = torch.zeros(b, (h // p) * (w // p), k_pad, dtype=torch.bfloat16, device=x.device)
+            patches[..., :k].view(b, h // p, w // p, c, p, p).copy_(unfolded)
+            cache = getattr(self, "_w_pad", None)
+            if cache is None or cache[0] != self.proj.weight._version or cache[1].device != x.device:
+                w_pad = torch.zeros(d, k_pad, dtype=torch.bfloat16, device=x.device)
+                w_pad[:, :k].copy_(self.proj.weight.reshape(d, k))
+                cache = (self.proj.weight._version, w_pad)
+                self._w_pad = cache
+            return ops.gemm_bf16(patches, cache[1], self.proj.bias)
+        if ops.handles(x):
+            library_fallback("patch embedding", f"K={k} D={d} dtype={x.dtype}")
         return F.linear(unfolded.reshape(b, -1, k), self.proj.weight.reshape(d, -1), self.proj.bias)
 
     def _bf16_compute(self, x) -> bool:
