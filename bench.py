@@ -72,6 +72,9 @@ class KernelTimer:
                 out = _fn(*a, **k)
                 e.record()
                 self.records[_name].append((s, e))
+                if _name in ("gemm_bf16", "gemm_gelu_fwd", "gemm_gelu_bwd"):
+                    # (rows, N, K) of y = x w^T: a[0] [..., K], a[1] [N, K]
+                    self.meta[_name].append((a[0].numel() // a[0].shape[-1], a[1].shape[0], a[1].shape[1], s, e))
                 if _name == "jacobi_svd":
                     # (batch, n_cols, m_rows, rank-masked?) -- masked launches sweep a smaller block
                     self.meta[_name].append((a[0].shape[0], a[0].shape[1], a[1], k.get("active") is not None, s, e, out[1]))
@@ -101,13 +104,14 @@ class KernelTimer:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (default: c2, "
                     "the one the metric is quoted on)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU baseline sample (default: the metric's 256 images: one timed CPU step, ~30 s on 16 cores)")
+    ap.add_argument("--global-batch", type=int, default=None, help="STRONG scaling: fix the global batch (e.g. 256) and give every rank global / world images; default: weak scaling, --batch images per GPU")
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-ab", action="store_true", help="skip the second, unpipelined measurement (profiling runs)")
@@ -117,6 +121,13 @@ def main():
     student_preset, teacher_preset, img_size, patch, cfg_batch, F_STUDENT, F_TEACHER, workload = CONFIGS[args.config]
     if args.batch is None:
         args.batch = cfg_batch
+    scaling = "weak"
+    if args.global_batch is not None:
+        w_ = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.global_batch % w_:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by the world size {w_}")
+        args.batch = args.global_batch // w_
+        scaling = "strong"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,7 +173,8 @@ def main():
     trainer.model.train()
 
     timer = KernelTimer(native, ["jacobi_svd", "pchol", "trinv", "bgemm_f64", "token_gram", "mix_tokens",
-                                 "mix_grad_dots", "procrustes_prep", "wgrad_bf16", "sf_adamw_step", "mp_rank"])
+                                 "mix_grad_dots", "procrustes_prep", "wgrad_bf16", "sf_adamw_step", "mp_rank",
+                                 "gemm_bf16", "gemm_gelu_fwd", "gemm_gelu_bwd"])
     timer.install()
 
     # a few eager steps first: rank sanity check + (events cannot be recorded inside a captured graph)
@@ -283,9 +295,9 @@ def main():
                      if big >= 512 and big_n <= 192 else
                      "basd::jacobi_oe_kernel (register-resident one-sided Jacobi, odd-even ordering")
             roof = {"kernel": f"{kname}, the E*B = {big} Procrustes cores of a step, {big_n}x{big_n} each)",
-                    # the contract's vocabulary has "hbm" | "mfma" only; this kernel is VALU-issue-bound and is priced
-                    # against the fp32 vector peak, which equals the fp32 MFMA peak on gfx950 (157.3 TF)
-                    "bound": "mfma", "bound_detail": "fp32 VALU kernel priced against the fp32 vector peak (= fp32 MFMA peak, 157.3 TF/s); "
+                    # this kernel is VALU-issue-bound (neither of the contract's "hbm" | "mfma"): priced against the fp32
+                    # vector peak, which equals the fp32 MFMA peak on gfx950 (157.3 TF)
+                    "bound": "valu", "bound_detail": "fp32 VALU kernel priced against the fp32 vector peak (= fp32 MFMA peak, 157.3 TF/s); "
                     "VALU-issue-bound (one workgroup per CU runs it as fast as two; 57 v_pk_fma_f32 + 22 v_fmac + ~20 other "
                     "VALU instructions per rotation and wave) plus the hand-over chain of its 6 waves",
                     "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
@@ -302,24 +314,52 @@ def main():
                     "note": "VALU kernel priced against the fp32 vector = matrix peak; algorithmic (textbook) "
                             "flops = sweeps actually run (returned per matrix by the kernel) x n(n-1)/2 pairs x 14 m; the "
                             "kernel EXECUTES ~10 m per pair (incremental norms), i.e. 0.71 x this figure (DESIGN.md section 5)"}
+        # ---- the kernel family with the largest TOTAL time: the bf16 GEMM of the ViT blocks (teacher forward, student
+        # forward + input gradients), algorithmic flops 2 M N K over the device-event time of the same probe steps
+        gemm = None
+        g_flops, g_ms, g_n = 0.0, 0.0, 0
+        by_shape = {}
+        for name in ("gemm_bf16", "gemm_gelu_fwd", "gemm_gelu_bwd"):
+            for (rows, n_, k_, ev_s, ev_e) in timer.meta.get(name, []):
+                ms = ev_s.elapsed_time(ev_e)
+                g_flops += 2.0 * rows * n_ * k_
+                g_ms += ms
+                g_n += 1
+                rec = by_shape.setdefault(f"{rows}x{n_}x{k_}", [0, 0.0, 2.0 * rows * n_ * k_])
+                rec[0] += 1
+                rec[1] += ms
+        if g_n:
+            ach = g_flops / (g_ms / 1e3) / 1e12
+            top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:4]
+            gemm = {"kernel": "basd::gemm_bf16_pring_kernel / gemm_bf16_nt_kernel (bf16 MFMA 16x16x32, LDS-DMA operand ring)",
+                    "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                    "launches_per_step": g_n / probe_steps, "ms_per_step": g_ms / probe_steps,
+                    "largest_shapes": {k_: {"launches_per_step": v_[0] / probe_steps, "avg_us": 1e3 * v_[1] / v_[0],
+                                            "tflops": v_[2] * v_[0] / (v_[1] / 1e3) / 1e12} for k_, v_ in top},
+                    "measured_in": "device events around every GEMM entry in the instrumented eager probe steps "
+                                   "(single stream: the GEMMs have the GPU to themselves there)"}
         vit_flops = global_batch * ((4 if args.grad_checkpointing else 3) * F_STUDENT + F_TEACHER)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_step import cpu_step_images_per_sec
             print("[bench] GPU timing done; timing the CPU baseline sample", file=sys.stderr, flush=True)
-            cpu = cpu_step_images_per_sec(batch=args.cpu_batch, timed_steps=3, warmup=1)
+            # the metric's own batch (256): one timed step, no warm-up step (~30 s of CPU work on the 16-core share)
+            small = args.cpu_batch < 128
+            cpu = cpu_step_images_per_sec(batch=args.cpu_batch, timed_steps=3 if small else 1, warmup=1 if small else 0)
         line = {
             "metric": ("images/sec BASD train step, DeiT-T student / ViT-B teacher bs=256" if args.config == "c2" else
                        f"images/sec BASD train step, {student_preset} student / {teacher_preset} teacher"),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{workload} (random init), {img_size}x{img_size}, E=4 extraction points, "
                                    "loss linalg fp32/fp64",
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "grad_checkpointing": bool(args.grad_checkpointing)},
             "roofline": roof,
+            "roofline_top_by_total_time": gemm,
             "cpu_baseline": cpu,
+            "library_fallbacks": dict(__import__("basd_amd.losses._ops", fromlist=["FALLBACKS"]).FALLBACKS),
             "vit_gemm": {"algorithmic_tflop_per_step": vit_flops / 1e12,
                          "tflops_if_whole_step": vit_flops / (ms_per_step / 1e3) / 1e12, "peak_bf16": 2500.0},
             "kernel_ms_per_step": {k: v["total_ms"] / probe_steps for k, v in ks.items()},

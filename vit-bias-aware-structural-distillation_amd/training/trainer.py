@@ -86,18 +86,21 @@ class Trainer:
         self.use_mixup = True
         self.autocast_dtype = torch.bfloat16
         self.overlap_teacher_stats = True
-        # Teacher forward next to the student forward (two streams of library GEMMs): measured -2.6 ms/step at the
-        # DeiT-T / ViT-B configuration, but at ViT-B / ViT-H shapes (BASELINE c5, 256 images) the two branches DEADLOCK on
-        # the GPU -- the library's persistent GEMM kernels spin on peers that are never scheduled once both grids
-        # compete for the CUs (reproduced three times; serialised launches or a single GEMM stream run fine).  So the
-        # overlap is on only for the narrow configuration it was validated on, unless basd.overlap_teacher_forward /
-        # BASD_OVERLAP_TEACHER force it either way; the teacher STATISTICS (hand-written kernels) still run on the side
-        # stream.
+        # Two streams.  The teacher branch (forward + its selector statistics) runs on a side stream next to the student
+        # forward (per-step schedule) or, pipelined across steps, next to loss / backward of the previous batch.  Round 2
+        # saw the GPU DEADLOCK at ViT-B / ViT-H shapes when both streams carried library GEMMs (three runs; no trace of
+        # them survives, so the cause -- persistent library kernels spinning on peers that get no CU -- is a hypothesis,
+        # not a finding).  The rule that follows from it is structural, not a width heuristic: the main stream always
+        # has library GEMMs (the 1000-class head, the fp32 products of the loss backward), so the side stream may exist
+        # only if the teacher branch enqueues NONE.  ``_ensure_stream_policy`` runs that branch once on the main stream
+        # under a recorder before any two-stream step; with the hand-written GEMM / attention / patch-embedding / wide
+        # token-Gram kernels every BASELINE configuration passes.  basd.overlap_teacher_forward / BASD_OVERLAP_TEACHER =
+        # false turns the forward overlap off; forcing it on while the branch does use library GEMMs is refused.
         forced = config.basd.get("overlap_teacher_forward", os.environ.get("BASD_OVERLAP_TEACHER"))
-        if forced is None or str(forced).lower() == "auto":
-            self.overlap_teacher_forward = student_info["embed_dim"] <= 192 and teacher.embed_dim <= 768
-        else:
-            self.overlap_teacher_forward = str(forced).lower() in ("1", "true")
+        self._overlap_forced = forced is not None and str(forced).lower() in ("1", "true")
+        self.overlap_teacher_forward = forced is None or str(forced).lower() in ("auto", "1", "true")
+        self._stream_policy_done = False
+        self.two_stream_refused = None          # library GEMM call sites of the teacher branch, if any were found
         # Software pipelining of the frozen teacher ACROSS steps (captured steps only): while loss / backward of batch k
         # run, the side stream computes the teacher forward + selector statistics of batch k + 1 into the other of two
         # held sets, so the step never waits for the teacher and the latency-bound kernels of the loss no longer leave
@@ -128,9 +131,33 @@ class Trainer:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def _ensure_stream_policy(self, clean) -> None:
+        """Decide ONCE, before the first two-stream step, whether the teacher branch may have a stream of its own: it is
+        run on the current stream under a recorder of library GEMM call sites (losses/_ops.py); any hit serialises the
+        step (no side stream, no cross-step pipelining) -- or raises, if the overlap was forced by the configuration."""
+        if self._stream_policy_done or self.device.type != "cuda":
+            return
+        self._stream_policy_done = True
+        from ..losses._ops import record_library_gemms
+        sel = self.basd_loss.layer_selector
+        with record_library_gemms() as seen, torch.no_grad():
+            self._teacher_branch(clean)
+        sel._frames = None
+        torch.cuda.current_stream().synchronize()
+        if seen:
+            self.two_stream_refused = sorted(seen)
+            if self._overlap_forced:
+                raise ValueError("basd.overlap_teacher_forward is forced on, but the teacher branch enqueues library GEMMs "
+                                 f"({', '.join(self.two_stream_refused)}): two streams of library GEMMs deadlocked the GPU "
+                                 "in round 2; refusing")
+            self.overlap_teacher_stats = False
+            self.overlap_teacher_forward = False
+            self.pipeline_teacher = False
+
     # ------------------------------------------------------------------ step
     def _forward_backward(self, clean, student_imgs, mixed_targets):
         """teacher fwd -> (side stream) teacher statistics || student fwd -> loss -> backward."""
+        self._ensure_stream_policy(clean)
         self.flat.refresh_bf16()          # one cast kernel for every Linear weight of the student
         # The frozen teacher and its selector statistics (12 Gram passes + 24 small eigenproblems that
         # occupy 24 of the 256 CUs) are independent of the student forward.  overlap_teacher_forward:
@@ -297,7 +324,7 @@ class Trainer:
             torch.cuda.synchronize()
             self._graph_pool = None
             self._pipe = None
-            want_pipe = self.pipeline_teacher if pipeline is None else pipeline
+            want_pipe = (self.pipeline_teacher if pipeline is None else pipeline) and self.two_stream_refused is None
             if want_pipe and len(self._teacher.layer_paths) > 1:
                 try:
                     self._enable_pipeline(warmup)
