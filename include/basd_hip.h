@@ -155,6 +155,12 @@ int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int nor
 int basd_mp_rank(const float* evals, int batch, int n, int64_t rows, int d, int cap,
                  int32_t* ranks, int32_t* status, void* stream);
 
+/* Data-dependent failure raised from host-orchestrated checks (the blocked eigensolver's orthogonality test): ORs
+ * `bit` (a BASD_STATUS_* value) into the device health word if any of the n fp64 values is NOT <= tol -- a NaN raises it
+ * too -- with an atomic OR (the word is shared with kernels of other streams).  Counterpart of the
+ * torch._C._LinAlgError the reference's torch.linalg calls raise (layer_selector.py:16,36,92,99). */
+int basd_flag_if_exceeds_f64(const double* values, int64_t n, double tol, int bit, int32_t* status, void* stream);
+
 /* Principal-angle distances -> mixing weights of the Grassmannian selector, fused (reference
  * src/losses/layer_selector.py:100-108).  sigma [E, L, D] fp32: cosines of the principal angles between student
  * extraction point i and teacher layer j (descending; zero beyond the layer's rank), sw [L, D] fp32: the teacher's

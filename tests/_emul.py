@@ -27,6 +27,11 @@ def status_word(device=None):
     return _STATUS
 
 
+def flag_if_exceeds(values, tol, bit):
+    if bool((~(values.double() <= tol)).any()):
+        _STATUS.bitwise_or_(torch.tensor([bit], dtype=torch.int32))
+
+
 def raise_for_status(value):
     from basd_amd._native import raise_for_status as real
     real(value)

@@ -359,3 +359,36 @@ def test_a_library_gemm_in_the_teacher_branch_serialises_the_step(monkeypatch):
     forced._overlap_forced = True
     with pytest.raises(ValueError, match="library GEMMs"):
         forced.train_step(batch)
+
+
+def test_the_training_loop_runs_the_captured_pipelined_step():
+    """Trainer._train_epoch (what Trainer.train / train.py run) captures the step on its first batch -- the pipelined
+    pair of graphs for a ViT teacher -- instead of staying on the eager schedule"""
+    from basd_amd.train import SyntheticLoader
+    trainer, _ = _make(32)
+    assert trainer._graph is None and trainer.capture_step
+    metrics = trainer._train_epoch(SyntheticLoader(32, 32, 100, 4, "cuda", seed=9))
+    assert trainer._graph is not None and trainer._pipe is not None, (trainer.graph_error, trainer.pipeline_error)
+    assert metrics["train_loss"] == metrics["train_loss"] and trainer.optimizer.k == 4
+
+
+def test_an_in_place_refilled_batch_buffer_is_not_mistaken_for_the_same_batch():
+    """a loader that refills ONE static device buffer passes an identity test with new contents: the held teacher
+    outputs are keyed on (tensor, version), so the refilled batch gets its own teacher pass"""
+    from basd_amd.train import SyntheticLoader
+    fresh = [next(iter(SyntheticLoader(32, 32, 100, 1, "cuda", seed=80 + i))) for i in range(3)]
+    ref, _ = _make(32)
+    assert ref.enable_graph(fresh[0], pipeline=False)
+    want = [float(ref.train_step(b)[0]) for b in fresh]
+    trainer, _ = _make(32)
+    static = {k: v.clone() for k, v in fresh[0].items()}
+    assert trainer.enable_graph(static, pipeline=True) and trainer._pipe is not None
+    got = []
+    for b in fresh:
+        for k in static:
+            static[k].copy_(b[k])                 # same tensor objects, new contents
+        got.append(float(trainer.train_step(static)[0]))
+    trainer.check_health()
+    assert abs(got[0] - want[0]) <= 1e-5 * abs(want[0])
+    for a_, b_ in zip(got, want):
+        assert abs(a_ - b_) <= 5e-3 * abs(b_), (got, want)

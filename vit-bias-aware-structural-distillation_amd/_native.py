@@ -20,7 +20,7 @@ JACOBI_LDS_BYTES = 163840
 
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
-    "basd_mp_rank", "basd_angle_weights", "basd_ce_uwso",
+    "basd_mp_rank", "basd_flag_if_exceeds_f64", "basd_angle_weights", "basd_ce_uwso",
     "basd_procrustes_workspace_bytes", "basd_procrustes_fwd", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
     "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
@@ -39,6 +39,7 @@ _SIGNATURES = {
     "basd_trinv_f64": (_P, _P, _P, _I, _I, _P, _P),
     "basd_jacobi_svd": (_P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _I, _P, _P),
     "basd_mp_rank": (_P, _I, _I, _I64, _I, _I, _P, _P, _P),
+    "basd_flag_if_exceeds_f64": (_P, _I64, _D, _I, _P, _P),
     "basd_angle_weights": (_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P),
     "basd_mix_tokens": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
     "basd_procrustes_prep": (_P, _I, _I64, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P),
@@ -349,6 +350,15 @@ def mp_rank(evals: torch.Tensor, rows: int, d: int, cap: int) -> torch.Tensor:
     return ranks
 
 
+def flag_if_exceeds(values: torch.Tensor, tol: float, bit: int) -> None:
+    """OR ``bit`` into the device health word if any entry of ``values`` (fp64) is not <= tol (NaN included): atomic,
+    no host sync."""
+    _need_cuda(values)
+    v = values.detach().reshape(-1).to(torch.float64).contiguous()
+    _check(lib().basd_flag_if_exceeds_f64(_ptr(v), ctypes.c_int64(v.numel()), ctypes.c_double(tol), int(bit),
+                                          _ptr(status_word(v.device)), _stream()), "basd_flag_if_exceeds_f64")
+
+
 def angle_weights(sigma: torch.Tensor, sw: torch.Tensor, log_temp: torch.Tensor, unnormalised: bool):
     """sigma [E, L, D] cosines, sw [L, D] masked teacher singular values, log_temp [E] ->
     (d2 [E, L], pre [E, L], weights [E, L], coef [E, L, D]) fp32; see basd_angle_weights."""
@@ -477,30 +487,66 @@ def lerp_(y, z, w: float) -> None:
     _check(lib().basd_lerp(_ptr(y), _ptr(z), ctypes.c_int64(y.numel()), ctypes.c_float(w), _stream()), "basd_lerp")
 
 
-_PROCRUSTES_WS: dict = {}
+# Scratch buffers of the workspace entries (basd_procrustes_fwd, basd_wgrad_bf16_ws): one per (kind, device), grown on
+# demand.  A buffer that has been handed out is NEVER freed -- a captured hipGraph keeps replaying into the address it
+# was captured with, so an outgrown buffer is parked in ``_RETIRED`` instead of being released -- and a call from a
+# stream other than the buffer's last user is ordered behind that user (event wait), so two streams (or two trainers)
+# sharing a device never write the same scratch concurrently.
+_SCRATCH: dict = {}
+_RETIRED: list = []
+
+
+class _Scratch:
+    __slots__ = ("buf", "stream", "event", "shared")
+
+    def __init__(self, buf, stream):
+        self.buf, self.stream, self.event, self.shared = buf, stream, None, False
+
+
+def _scratch(kind: str, device: torch.device, nbytes: int, min_bytes: int = 0) -> "_Scratch":
+    key = (kind, device.index)
+    cur = torch.cuda.current_stream(device)
+    rec = _SCRATCH.get(key)
+    if rec is None or rec.buf.numel() < nbytes:
+        if rec is not None:
+            _RETIRED.append(rec.buf)
+        rec = _SCRATCH[key] = _Scratch(torch.empty(max(nbytes, min_bytes), dtype=torch.uint8, device=device), cur)
+    elif rec.stream.cuda_stream != cur.cuda_stream:
+        if rec.event is not None:
+            cur.wait_event(rec.event)
+        else:
+            cur.wait_stream(rec.stream)
+        rec.shared = True                       # from now on every use leaves an event behind
+        rec.stream = cur
+    return rec
+
+
+def _scratch_used(rec: "_Scratch") -> None:
+    if rec.shared:
+        rec.event = torch.cuda.Event()
+        rec.event.record(rec.stream)
+
 
 
 def procrustes_fwd(s_w: torch.Tensor, t_w: torch.Tensor, tol: float = 1e-13):
     """s_w [batch, n, d_s], t_w [batch, n, d_t] fp32 (weighted, centred tokens from ``procrustes_prep``) ->
     (nuc [batch], fac_s, a_t [batch, n, n]) fp32; fac_s = t_w G^T [batch, n, d_s] if n > d_s else a_s [batch, n, n]
-    (see basd_procrustes_fwd).  One C call; the scratch (per device, grown on demand, shared by the calls of a stream)
-    comes from torch's allocator outside any graph capture."""
+    (see basd_procrustes_fwd).  One C call; the scratch comes from ``_scratch`` (per device, never freed once used)."""
     _need_cuda(s_w, t_w)
     assert s_w.dtype == torch.float32 and t_w.dtype == torch.float32 and s_w.shape[:2] == t_w.shape[:2]
     s_w, t_w = s_w.contiguous(), t_w.contiguous()
     batch, n, d_s = s_w.shape
     d_t = t_w.shape[2]
     need = int(lib().basd_procrustes_workspace_bytes(batch, n, d_s, d_t))
-    ws = _PROCRUSTES_WS.get(s_w.device.index)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=s_w.device)
-        _PROCRUSTES_WS[s_w.device.index] = ws
+    rec = _scratch("procrustes", s_w.device, need)
+    ws = rec.buf
     nuc = torch.empty(batch, dtype=torch.float32, device=s_w.device)
     fac_s = torch.empty(batch, n, d_s if n > d_s else n, dtype=torch.float32, device=s_w.device)
     a_t = torch.empty(batch, n, n, dtype=torch.float32, device=s_w.device)
     _check(lib().basd_procrustes_fwd(_ptr(s_w), _ptr(t_w), batch, n, d_s, d_t, ctypes.c_double(tol), _ptr(nuc),
                                      _ptr(fac_s), _ptr(a_t), _ptr(status_word(s_w.device)), _ptr(ws),
                                      ctypes.c_int64(ws.numel()), _stream()), "basd_procrustes_fwd")
+    _scratch_used(rec)
     return nuc, fac_s, a_t
 
 
@@ -659,28 +705,14 @@ def wgrad_bf16(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True, out_w:
     assert dw.is_contiguous() and dw.dtype == torch.float32 and dw.shape == (n, k)
     need = int(lib().basd_wgrad_workspace_bytes(ctypes.c_int64(m), n, k))
     if need > 0:
-        ws = _wgrad_workspace(dy.device, need)
-        _check(lib().basd_wgrad_bf16_ws(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _ptr(ws),
-                                        ctypes.c_int64(ws.numel() * 4), _stream()), "basd_wgrad_bf16_ws")
+        rec = _scratch("wgrad", dy.device, need, min_bytes=256 * 192 * 192 * 4)
+        _check(lib().basd_wgrad_bf16_ws(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _ptr(rec.buf),
+                                        ctypes.c_int64(rec.buf.numel()), _stream()), "basd_wgrad_bf16_ws")
+        _scratch_used(rec)
     else:
         _check(lib().basd_wgrad_bf16(_ptr(dy), _ptr(x), ctypes.c_int64(m), n, k, _ptr(dw), _ptr(db), _stream()),
                "basd_wgrad_bf16")
     return dw, db
-
-
-_WGRAD_WS: dict = {}
-
-
-def _wgrad_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """scratch for the partial tiles of basd_wgrad_bf16_ws, one per device (<= 37.75 MB): the weight-gradient launches
-    of a backward pass run one after the other on one stream and share it; it is allocated by the first call, i.e. by
-    the warm-up steps before any graph capture"""
-    key = device.index
-    ws = _WGRAD_WS.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(max(nbytes, 256 * 192 * 192 * 4) // 4, dtype=torch.float32, device=device)
-        _WGRAD_WS[key] = ws
-    return ws
 
 
 def cls_importance_supported(t: int, hd: int) -> bool:

@@ -82,3 +82,27 @@ extern "C" int basd_angle_weights(const float* sigma, const float* sw, const flo
                      unnormalised, d2, pre, weights, coef);
   return check_launch("angle_weights");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Raise a status bit if any of n fp64 values is NOT <= tol (so a NaN raises it too), with an atomic OR: the health word
+// is shared with the kernels of the other stream, which atomicOr into it concurrently (a torch bitwise_or_ is a plain
+// read-modify-write and can lose their flag).
+namespace basd {
+__global__ __launch_bounds__(256) void flag_if_exceeds_kernel(const double* __restrict__ v, int64_t n, double tol,
+                                                              int bit, int* __restrict__ status) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= !(v[i] <= tol);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, bit);
+}
+}  // namespace basd
+
+extern "C" int basd_flag_if_exceeds_f64(const double* values, int64_t n, double tol, int bit, int32_t* status,
+                                        void* stream) {
+  using namespace basd;
+  if (n <= 0 || status == nullptr) return BASD_OK;
+  const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  hipLaunchKernelGGL(flag_if_exceeds_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, values, n, tol, bit,
+                     (int*)status);
+  return check_launch("flag_if_exceeds");
+}
+

@@ -196,8 +196,8 @@ def _psd_eig_blocked(a64: torch.Tensor):
     nrm2 = torch.diagonal(gram, dim1=-2, dim2=-1)
     live = (nrm2 > 0).to(gram.dtype)                                      # columns dropped at the rank are exact zeros
     scale = torch.rsqrt(nrm2.clamp_min(1e-300)) * live
-    cosmax = (gram * scale.unsqueeze(-1) * scale.unsqueeze(-2) - torch.diag_embed(live)).abs().amax()
-    ops.status_word(x.device).bitwise_or_((cosmax > WIDE_COS_TOL).to(torch.int32) * ops.STATUS_NONCONVERGED)
+    cosmax = (gram * scale.unsqueeze(-1) * scale.unsqueeze(-2) - torch.diag_embed(live)).abs().amax(dim=(-2, -1))
+    ops.flag_if_exceeds(cosmax, WIDE_COS_TOL, ops.STATUS_NONCONVERGED)        # atomic OR; a NaN raises the flag too
     nrm = nrm2.sqrt()                                                     # [b, n_pad] singular values = column norms
     order = torch.argsort(nrm, dim=-1, descending=True, stable=True)[:, :n]
     sigma = torch.gather(nrm, 1, order).float()
