@@ -131,6 +131,21 @@ def _trainer_worker(rank, world, port, out_dir):
     trainer._forward_backward(batch["clean"], batch["augmented"], batch["label"])
     trainer.reducer.reduce_all()
     out["grad_all"] = trainer.flat.grad.clone()
+    trainer.flat.zero_grad()
+    # path 3: the two-stage backward of a captured multi-rank step -- stage 1 (loss ... block cut), the late slice of the
+    # flat buffer all-reduced asynchronously, stage 2 (blocks below the cut) under it, then the early slice
+    seg = trainer._segment_spec()
+    assert seg is not None and 0 < seg["offset"] < trainer.flat.numel and seg["cut"] == 4
+    trainer._forward_backward(batch["clean"], batch["augmented"], batch["label"], split=True)
+    early_before = trainer.flat.grad[:seg["offset"]].clone()
+    trainer.reducer.reduce_range_async(seg["offset"], trainer.flat.numel)
+    trainer._backward_stage2()
+    trainer.reducer.reduce_range_async(0, seg["offset"])
+    trainer.reducer.wait_ranges()
+    out["grad_split"] = trainer.flat.grad.clone()
+    # stage 1 leaves the early slice untouched except for block cut's first norm (unfused CPU path: applied in stage 1)
+    out["early_touched_in_stage1"] = int((early_before != 0).sum())
+    trainer.reducer.paused = False
     n_t = trainer.basd_loss.layer_selector.log_temperatures.numel()
     out["temp_grad"] = trainer.basd_loss.layer_selector.log_temperatures.grad.clone()
     assert n_t == 4
@@ -160,6 +175,8 @@ def test_two_rank_trainer_shards_losses_and_gradient_mean(tmp_path):
         torch.testing.assert_close(got[r]["loss"], want_loss[r], rtol=1e-6, atol=0)       # (i) per-rank loss on its shard
         torch.testing.assert_close(got[r]["grad_hooks"], want_grad, rtol=1e-5, atol=1e-7)  # (ii) finish()
         torch.testing.assert_close(got[r]["grad_all"], want_grad, rtol=1e-5, atol=1e-7)    # (ii) reduce_all()
+        torch.testing.assert_close(got[r]["grad_split"], want_grad, rtol=1e-5, atol=1e-7)  # (ii) two-stage backward
+        assert got[r]["early_touched_in_stage1"] <= 2 * 192
     torch.testing.assert_close(got[0]["grad_hooks"], got[1]["grad_hooks"], rtol=0, atol=0)
     # (iii) the four temperatures sit in the same flat buffer: averaged, identical on both ranks, and not zero
     torch.testing.assert_close(got[0]["temp_grad"], got[1]["temp_grad"], rtol=0, atol=0)

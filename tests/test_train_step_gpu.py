@@ -10,11 +10,11 @@ CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                    "vit-bias-aware-structural-distillation_amd", "configs", "config.yaml")
 
 
-def _make(batch):
+def _make(batch, extra=()):
     from basd_amd.config import load_config
     from basd_amd.train import SyntheticLoader, build
     torch.manual_seed(0)
-    cfg = load_config(CFG, "basd_cifar100", [f"data.batch_size={batch}", "model.drop_path_rate=0.0"])
+    cfg = load_config(CFG, "basd_cifar100", [f"data.batch_size={batch}", "model.drop_path_rate=0.0", *extra])
     trainer, _ = build(cfg, device="cuda")
     trainer.use_mixup = False
     trainer.optimizer.train()
@@ -392,3 +392,28 @@ def test_an_in_place_refilled_batch_buffer_is_not_mistaken_for_the_same_batch():
     assert abs(got[0] - want[0]) <= 1e-5 * abs(want[0])
     for a_, b_ in zip(got, want):
         assert abs(a_ - b_) <= 5e-3 * abs(b_), (got, want)
+
+
+@pytest.mark.parametrize("pipe", [False, True])
+def test_two_stage_captured_backward_equals_the_single_graph(pipe):
+    """what a multi-rank run captures (graph A: forward, loss, backward down to the second extraction point; the late
+    gradient slice is all-reduced while graph B finishes the backward) against the one-graph step, forced on one rank:
+    same losses and weights; eager two-stage step 0 equals the plain eager step"""
+    from basd_amd.train import SyntheticLoader
+    batches = [next(iter(SyntheticLoader(32, 32, 100, 1, "cuda", seed=90 + i))) for i in range(2)]
+    runs = {}
+    for seg in (False, True):
+        trainer, _ = _make(32, ["basd.segmented_backward=true"] if seg else [])
+        assert trainer.segmented == seg
+        l_eager = float(trainer.train_step(batches[0], batches[1])[0])
+        assert trainer.enable_graph(batches[1], pipeline=pipe), trainer.graph_error
+        tails = trainer._pipe["tails"] if trainer._pipe is not None else [trainer._graph_tail]
+        assert all((t is not None) == seg for t in tails) and (trainer._pipe is not None) == pipe
+        losses = [l_eager] + [float(trainer.train_step(batches[(i + 1) % 2], batches[i % 2])[0]) for i in range(4)]
+        trainer.check_health()
+        runs[seg] = (losses, trainer.flat.data.clone())
+    assert abs(runs[True][0][0] - runs[False][0][0]) <= 1e-5 * abs(runs[False][0][0])
+    for a_, b_ in zip(runs[True][0], runs[False][0]):
+        assert abs(a_ - b_) <= 5e-3 * abs(b_), (runs[True][0], runs[False][0])
+    rel = float((runs[True][1] - runs[False][1]).norm() / runs[False][1].norm())
+    assert rel < 2e-3, rel

@@ -106,6 +106,21 @@ class GradientReducer:
         dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.grad.div_(self.world)
 
+    def reduce_range_async(self, start: int, end: int) -> None:
+        """all-reduce of a contiguous slice of the flat gradient buffer, asynchronously (two-stage captured backward:
+        the late parameters' slice is launched between the two graph replays and flies under the second one)"""
+        if self.enabled and end > start:
+            self._handles.append(dist.all_reduce(self.flat.grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+
+    def wait_ranges(self) -> None:
+        if not self.enabled:
+            return
+        for h in self._handles:
+            h.wait()
+        self._handles.clear()
+        self.flat.grad.div_(self.world)
+
     def broadcast_parameters(self, src: int = 0):
         if self.enabled:
             dist.broadcast(self.flat.data, src=src, group=self.group)

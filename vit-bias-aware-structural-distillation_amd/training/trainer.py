@@ -79,6 +79,7 @@ class Trainer:
             bucket_bytes = int(float(config.basd.bucket_mb) * (1 << 20))
         self.reducer = GradientReducer(self.flat, bucket_bytes=bucket_bytes)
         self.reducer.broadcast_parameters()
+        self._force_segmented = str(config.basd.get("segmented_backward", "false")).lower() in ("1", "true")
         self.optimizer.z.copy_(self.flat.data)
         self.best_val_acc = 0.0
         self.metrics_history = defaultdict(list)
@@ -101,6 +102,12 @@ class Trainer:
         self.overlap_teacher_forward = forced is None or str(forced).lower() in ("auto", "1", "true")
         self._stream_policy_done = False
         self.two_stream_refused = None          # library GEMM call sites of the teacher branch, if any were found
+        self._seg_spec = None
+        self._seg_pending = None
+        self._seg_late = None
+        # backward in two stages with the late gradients all-reduced under the second one: whenever gradients are
+        # reduced at all (basd.segmented_backward forces it on a single rank: tests)
+        self.segmented = self.reducer.enabled or self._force_segmented
         # Software pipelining of the frozen teacher ACROSS steps (captured steps only): while loss / backward of batch k
         # run, the side stream computes the teacher forward + selector statistics of batch k + 1 into the other of two
         # held sets, so the step never waits for the teacher and the latency-bound kernels of the loss no longer leave
@@ -122,6 +129,7 @@ class Trainer:
         self._graph_pool = None
         self._side = None
         self._graph = None
+        self._graph_tail = None
         self.graph_error = None
         # pinned copies of the kernels' health word still in flight, oldest first: (event, host tensor); read late
         self._status_pending = collections.deque()
@@ -157,10 +165,75 @@ class Trainer:
             self.overlap_teacher_forward = False
             self.pipeline_teacher = False
 
+    # ------------------------------------------------- backward in two stages
+    # With several ranks the gradients are all-reduced (reference: DDP's bucket overlap, src/training/trainer.py:80-82).
+    # A captured step cannot run hooks, and a collective inside a hipGraph cannot be rehearsed on a one-GPU box, so the
+    # captured backward is CUT instead: stage 1 = loss -> head -> student blocks [cut, depth) (graph A), stage 2 = blocks
+    # [0, cut) + patch embedding (graph B).  The late parameters are a contiguous suffix of the flat gradient buffer: their
+    # all-reduce is launched between the two replays and flies under stage 2; the rest follows.  The cut sits at the
+    # second extraction point, so stage 2 is about a third of the student backward.  Autograd interface of the cut: the
+    # output of block cut - 1 (+ the fused pre-normalised tensor that travels with it) and the token taps below the cut.
+    def _segment_spec(self):
+        if self._seg_spec is None:
+            self._seg_spec = False
+            paths = self._student_layer_paths
+            layers = sorted(self.basd_loss.token_layers)
+            cut = layers[1] if len(layers) > 1 else len(paths) // 3
+            if 1 <= cut < len(paths) and not getattr(self.model, "grad_checkpointing", False):
+                blk = self.model.get_submodule(paths[cut])
+                # block cut's first norm is evaluated by the fused add + norm of block cut - 1 (stage 2): the late range
+                # starts behind it
+                named = [q for name, q in blk.named_parameters() if not name.startswith("norm1.")]
+                ids = {id(q): i for i, q in enumerate(self.flat.params)}
+                if named and id(named[0]) in ids:
+                    first = min(ids[id(q)] for q in named)
+                    norm1 = [q for name, q in blk.named_parameters() if name.startswith("norm1.") and id(q) in ids]
+                    self._seg_spec = {"cut": cut, "offset": self.flat.offsets[first], "late": self.flat.params[first:],
+                                      "norm1": norm1}
+        return self._seg_spec or None
+
+    def _student_forward(self, student_imgs, seg):
+        """student forward with the token taps; with ``seg`` also the autograd interface of the backward cut"""
+        holder, hook = {}, None
+        if seg is not None:
+            prev = self.model.get_submodule(self._student_layer_paths[seg["cut"] - 1])
+            hook = prev.register_forward_hook(lambda m, i, o: holder.__setitem__("out", o))
+        try:
+            with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
+                logits, s_tokens = _extract_student(self.model, student_imgs, self.basd_loss.token_layers,
+                                                    layer_paths=self._student_layer_paths,
+                                                    has_cls_token=self._student_has_cls)
+        finally:
+            if hook is not None:
+                hook.remove()
+        iface = None
+        if seg is not None:
+            out = holder["out"]
+            pre = getattr(out, "_basd_prenorm", None)
+            iface = [out] + ([pre[1]] if pre is not None else []) + [s_tokens[l] for l in sorted(s_tokens) if l < seg["cut"]]
+            # unfused path: block cut applies its own first norm, i.e. in stage 1
+            self._seg_late = (seg["late"] if pre is not None else seg["norm1"] + seg["late"])
+        return logits, s_tokens, iface
+
+    def _backward_stage1(self, loss, iface):
+        late = self._seg_late
+        grads = torch.autograd.grad([loss], late + iface, allow_unused=True)
+        for q, g in zip(late, grads[:len(late)]):
+            if g is not None:                     # parameters without a gradient sink (head, temperatures, ...)
+                q.grad.add_(g.to(q.grad.dtype))
+        self._seg_pending = [(t, g) for t, g in zip(iface, grads[len(late):]) if g is not None]
+
+    def _backward_stage2(self):
+        tensors, grads = zip(*self._seg_pending)
+        self._seg_pending = None
+        torch.autograd.backward(list(tensors), list(grads))
+
     # ------------------------------------------------------------------ step
-    def _forward_backward(self, clean, student_imgs, mixed_targets):
-        """teacher fwd -> (side stream) teacher statistics || student fwd -> loss -> backward."""
+    def _forward_backward(self, clean, student_imgs, mixed_targets, split=False):
+        """teacher fwd -> (side stream) teacher statistics || student fwd -> loss -> backward (``split``: stage 1 only,
+        ``_backward_stage2`` finishes it)."""
         self._ensure_stream_policy(clean)
+        seg = self._segment_spec() if split else None
         self.flat.refresh_bf16()          # one cast kernel for every Linear weight of the student
         # The frozen teacher and its selector statistics (12 Gram passes + 24 small eigenproblems that
         # occupy 24 of the 256 CUs) are independent of the student forward.  overlap_teacher_forward:
@@ -172,9 +245,7 @@ class Trainer:
         selector = self.basd_loss.layer_selector
 
         def student_forward():
-            with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
-                return _extract_student(self.model, student_imgs, self.basd_loss.token_layers,
-                                        layer_paths=self._student_layer_paths, has_cls_token=self._student_has_cls)
+            return self._student_forward(student_imgs, seg)
 
         if side is not None and self.overlap_teacher_forward:
             # Measured and rejected inside the captured graph (same-box A/B, ms per step): the teacher's Gram passes
@@ -185,7 +256,7 @@ class Trainer:
             with torch.cuda.stream(side):
                 t_tokens, t_importance = extract_intermediates(self._teacher, clean)
                 selector.precompute_teacher(t_tokens)
-            logits, s_tokens = student_forward()
+            logits, s_tokens, iface = student_forward()
         else:
             t_tokens, t_importance = extract_intermediates(self._teacher, clean)
             if side is not None:
@@ -193,7 +264,7 @@ class Trainer:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     selector.precompute_teacher(t_tokens)
-            logits, s_tokens = student_forward()
+            logits, s_tokens, iface = student_forward()
         # no join here: the selector waits for the side stream (event recorded by precompute_teacher) only
         # where it consumes the teacher frames, so the student's statistics overlap the teacher's
         loss = self.basd_loss(logits.float(), mixed_targets, s_tokens, t_tokens, t_importance)
@@ -205,7 +276,10 @@ class Trainer:
             for t in list(t_tokens.values()) + list(t_importance.values()):
                 if t is not None:
                     t.record_stream(main)
-        loss.backward()
+        if seg is not None:
+            self._backward_stage1(loss, iface)
+        else:
+            loss.backward()
         return loss.detach(), logits.detach()
 
     # ------------------------------------------------------- teacher pipeline
@@ -233,9 +307,11 @@ class Trainer:
                 if isinstance(v, torch.Tensor):
                     d[k].copy_(v)
 
-    def _piped_forward_backward(self, held, out_held, clean_next, student_imgs, mixed_targets):
+    def _piped_forward_backward(self, held, out_held, clean_next, student_imgs, mixed_targets, split=False):
         """student fwd -> loss -> backward of the CURRENT batch on the held teacher outputs, while the side stream runs
-        the teacher branch of the NEXT batch into ``out_held``"""
+        the teacher branch of the NEXT batch into ``out_held`` (``split``: backward stage 1 only; the side stream is
+        joined here, stage 2 -- a third of the student backward -- runs alone)"""
+        seg = self._segment_spec() if split else None
         self.flat.refresh_bf16()
         main, side = torch.cuda.current_stream(), self._side_stream()
         side.wait_stream(main)
@@ -243,12 +319,12 @@ class Trainer:
             self._held_copy(out_held, self._teacher_branch(clean_next))
         tokens, importance, (idx, frames) = held
         self.basd_loss.layer_selector._frames = (idx, dict(frames))
-        with torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype):
-            logits, s_tokens = _extract_student(self.model, student_imgs, self.basd_loss.token_layers,
-                                                layer_paths=self._student_layer_paths,
-                                                has_cls_token=self._student_has_cls)
+        logits, s_tokens, iface = self._student_forward(student_imgs, seg)
         loss = self.basd_loss(logits.float(), mixed_targets, s_tokens, tokens, importance)
-        loss.backward()
+        if seg is not None:
+            self._backward_stage1(loss, iface)
+        else:
+            loss.backward()
         main.wait_stream(side)
         return loss.detach(), logits.detach()
 
@@ -272,6 +348,24 @@ class Trainer:
                 self.flat.zero_grad()
         raise last
 
+    def _capture_step(self, fn):
+        """capture one step: fn(split) -> (loss, logits).  Segmented: graph A = fn(True) (everything up to backward stage
+        1), graph B = backward stage 2; otherwise one graph.  -> (graph A, graph B | None, outputs)"""
+        if self.segmented and self._segment_spec() is not None:
+            ga, out = self._capture(lambda: fn(True))
+            gb, _ = self._capture(lambda: (self._backward_stage2(), None)[1])
+            return ga, gb, out
+        g, out = self._capture(lambda: fn(False))
+        return g, None, out
+
+    def _run_step_fn(self, fn):
+        """eager execution of a step function with the schedule the capture will have (warm-up passes)"""
+        split = self.segmented and self._segment_spec() is not None
+        out = fn(split)
+        if split:
+            self._backward_stage2()
+        return out
+
     def _enable_pipeline(self, warmup: int) -> None:
         """two captured steps that ping-pong between two held sets of teacher outputs"""
         with torch.no_grad():
@@ -283,21 +377,22 @@ class Trainer:
         warm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(warm):
             for i in range(max(warmup, 2)):
-                self._piped_forward_backward(held[i & 1], held[1 - (i & 1)], self._g_clean_next, self._g_imgs,
-                                             self._g_targets)
+                self._run_step_fn(lambda split, i=i: self._piped_forward_backward(
+                    held[i & 1], held[1 - (i & 1)], self._g_clean_next, self._g_imgs, self._g_targets, split))
                 self.flat.zero_grad()
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
-        graphs, outs = [], []
+        graphs, tails, outs = [], [], []
         for p_ in (0, 1):
-            g, out = self._capture(lambda p_=p_: self._piped_forward_backward(held[p_], held[1 - p_], self._g_clean_next,
-                                                                                 self._g_imgs, self._g_targets))
+            g, gb, out = self._capture_step(lambda split, p_=p_: self._piped_forward_backward(
+                held[p_], held[1 - p_], self._g_clean_next, self._g_imgs, self._g_targets, split))
             self.flat.zero_grad()
             graphs.append(g)
+            tails.append(gb)
             outs.append(out)
         # held[0] was overwritten by the warm-up / capture passes: nothing is valid until a step fills it
-        self._pipe = {"graphs": graphs, "out": outs, "held": held, "cur": 0, "valid_for": None, "blind": 0,
-                      "announced": None}
+        self._pipe = {"graphs": graphs, "tails": tails, "out": outs, "held": held, "cur": 0, "valid_for": None,
+                      "blind": 0, "announced": None}
 
     def enable_graph(self, batch: dict, warmup: int = 3, pipeline: bool | None = None) -> bool:
         """Capture teacher fwd + student fwd + loss + backward into ONE hipGraph (static input
@@ -321,7 +416,8 @@ class Trainer:
             warm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(warm):
                 for _ in range(warmup):
-                    self._forward_backward(self._g_clean, self._g_imgs, self._g_targets)
+                    self._run_step_fn(lambda split: self._forward_backward(self._g_clean, self._g_imgs, self._g_targets,
+                                                                           split))
                     self.flat.zero_grad()
             torch.cuda.current_stream().wait_stream(warm)
             torch.cuda.synchronize()
@@ -339,21 +435,46 @@ class Trainer:
                     self.flat.zero_grad()
             if self._pipe is not None:
                 self._graph = self._pipe["graphs"][0]            # "a captured step exists" for the code below
+                self._graph_tail = None
                 self._g_loss, self._g_logits = self._pipe["out"][0]
             else:
-                graph, (self._g_loss, self._g_logits) = self._capture(
-                    lambda: self._forward_backward(self._g_clean, self._g_imgs, self._g_targets))
+                graph, tail, (self._g_loss, self._g_logits) = self._capture_step(
+                    lambda split: self._forward_backward(self._g_clean, self._g_imgs, self._g_targets, split))
                 self.flat.zero_grad()
-                self._graph = graph
-            return True
+                self._graph, self._graph_tail = graph, tail
+            return self._ranks_agree_on_capture()
         except Exception as exc:      # capture is an optimisation: never lose the run over it
             self._graph = None
+            self._graph_tail = None
             self._pipe = None
             self.reducer.paused = False
             self.graph_error = f"{type(exc).__name__}: {exc}"
             torch.cuda.synchronize()
             self.flat.zero_grad()
+            if self.reducer.enabled:              # vote "no capture" so that the other ranks drop theirs too
+                import torch.distributed as dist
+                vote = torch.zeros(3, dtype=torch.int64, device=self.device)
+                for op in (dist.ReduceOp.MIN, dist.ReduceOp.MAX):
+                    dist.all_reduce(vote.clone(), op=op, group=self.reducer.group)
             return False
+
+    def _ranks_agree_on_capture(self) -> bool:
+        """every rank must replay the same schedule (the all-reduce calls of the two-stage replay have to match in number
+        and size): if the captures differ between ranks, all of them drop to the eager step"""
+        if not self.reducer.enabled:
+            return True
+        import torch.distributed as dist
+        tail = self._pipe["tails"][0] if self._pipe is not None else self._graph_tail
+        mine = torch.tensor([1, int(self._pipe is not None), int(tail is not None)], dtype=torch.int64, device=self.device)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.reducer.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        if bool((lo == hi).all()):
+            return True
+        self._graph = self._graph_tail = self._pipe = None
+        self.reducer.paused = False
+        self.graph_error = "the ranks captured different schedules: all of them run the eager step"
+        return False
 
     # ---------------------------------------------------------------- health
     def _poll_status(self, drain: bool = False) -> None:
@@ -396,6 +517,19 @@ class Trainer:
         self._status_pending.append((event, host))
         if event is None:
             self._poll_status()
+
+    def _replay(self, graph, tail) -> None:
+        """replay a captured step and average the gradients over the ranks: with a two-stage capture the late parameters'
+        all-reduce runs under the second graph, otherwise one all-reduce follows the replay"""
+        graph.replay()
+        if tail is None:
+            self.reducer.reduce_all()
+            return
+        off = self._segment_spec()["offset"]
+        self.reducer.reduce_range_async(off, self.flat.numel)
+        tail.replay()
+        self.reducer.reduce_range_async(0, off)
+        self.reducer.wait_ranges()
 
     def train_step(self, batch: dict, next_batch: dict | None = None):
         """One optimisation step on a device-resident batch {"clean","augmented","label"}.  ``next_batch`` (optional):
@@ -456,10 +590,9 @@ class Trainer:
                 if mixed_targets.dim() == 1:
                     mixed_targets = torch.nn.functional.one_hot(mixed_targets, self.num_classes).float()
                 self._g_targets.copy_(mixed_targets)
-            pipe["graphs"][cur].replay()
+            self._replay(pipe["graphs"][cur], pipe["tails"][cur])
             loss, logits = pipe["out"][cur]
             pipe["valid_for"], pipe["cur"] = (upcoming, upcoming._version), cur ^ 1
-            self.reducer.reduce_all()
         elif self._graph is not None:
             self._g_clean.copy_(clean)
             if student_imgs is not self._g_imgs:
@@ -468,9 +601,20 @@ class Trainer:
                 if mixed_targets.dim() == 1:
                     mixed_targets = torch.nn.functional.one_hot(mixed_targets, self.num_classes).float()
                 self._g_targets.copy_(mixed_targets)
-            self._graph.replay()
+            self._replay(self._graph, self._graph_tail)
             loss, logits = self._g_loss, self._g_logits
-            self.reducer.reduce_all()
+        elif self._force_segmented and self._segment_spec() is not None:
+            # eager two-stage backward (tests; the eager default overlaps per bucket from the gradient hooks instead)
+            hooks_were_paused, self.reducer.paused = self.reducer.paused, True
+            try:
+                loss, logits = self._forward_backward(clean, student_imgs, mixed_targets, split=True)
+                off = self._segment_spec()["offset"]
+                self.reducer.reduce_range_async(off, self.flat.numel)
+                self._backward_stage2()
+                self.reducer.reduce_range_async(0, off)
+                self.reducer.wait_ranges()
+            finally:
+                self.reducer.paused = hooks_were_paused
         else:
             loss, logits = self._forward_backward(clean, student_imgs, mixed_targets)
             self.reducer.finish()
