@@ -61,6 +61,10 @@ def _lookup(root: dict, path: str):
 
 
 def _num_classes(name: str) -> int:
+    import os
+    if os.path.isdir(name):                 # a local dataset root: the class folders / class_names of its training split
+        from .data import dataset_info      # (reference src/resolvers.py:10 asks the dataset builder the same question)
+        return dataset_info(name)["num_classes"]
     if name not in _NUM_CLASSES:
         raise KeyError(f"dataset {name!r}: number of classes unknown offline; set model.num_classes explicitly")
     return _NUM_CLASSES[name]

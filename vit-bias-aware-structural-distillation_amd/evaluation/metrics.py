@@ -39,7 +39,6 @@ def evaluate_model(model: nn.Module, data_loader, criterion: nn.Module, *, num_c
     to a class subset (ImageNet-R / -A style robustness sets)."""
     model.eval()
     dev = _device_of(model)
-    k5 = min(5, num_classes)
     tally = torch.zeros(4, dtype=torch.float64, device=dev)        # hits@1, hits@5, summed loss, samples
     keep = None if valid_indices is None else torch.as_tensor(valid_indices, device=dev)
     for batch in data_loader:
@@ -48,7 +47,7 @@ def evaluate_model(model: nn.Module, data_loader, criterion: nn.Module, *, num_c
         logits = model(x).float()
         if keep is not None:
             logits = logits.index_select(1, keep)
-        top = logits.topk(k5, dim=1).indices
+        top = logits.topk(min(5, num_classes, logits.shape[1]), dim=1).indices     # a class subset may have < 5 columns
         hit = top.eq(y.unsqueeze(1))
         tally[0] += hit[:, 0].sum()
         tally[1] += hit.any(dim=1).sum()

@@ -142,15 +142,25 @@ def main(argv=None):
     config = load_config(args.config, args.experiment, args.overrides)
     trainer, info = build(config)
     print(f"student_probed embed_dim={info['embed_dim']} depth={info['depth']} num_tokens={info['num_tokens']}")
-    loader = SyntheticLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes,
-                             args.steps_per_epoch, trainer.device)
+    from .data import create_dataloaders, is_local_dataset
+    local = is_local_dataset(config.data.dataset)
+    if local:
+        # reference src/train.py:110-113: dual-view training batches (clean view normalised with the TEACHER's
+        # statistics) + the evaluation loader, here from a local dataset root
+        loader, val = create_dataloaders(config, teacher_stats=(trainer._teacher.mean, trainer._teacher.std))
+    elif config.data.dataset != "synthetic" and not os.environ.get("BASD_ALLOW_SYNTHETIC", "1") == "1":
+        raise SystemExit(f"data.dataset={config.data.dataset!r} is not a local directory (hub datasets need the network)")
+    else:
+        loader = SyntheticLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes,
+                                 args.steps_per_epoch, trainer.device)
     start_epoch = 0
     if config.checkpoint.get("resume_from"):            # reference src/train.py:147-149
         start_epoch = trainer.load_checkpoint(config.checkpoint.resume_from)
         print(f"resumed_from={config.checkpoint.resume_from} start_epoch={start_epoch}")
     from .evaluation import evaluate_model, run_eval_suite, save_metrics
-    val = SyntheticEvalLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes, 2,
-                              trainer.device)
+    if not local:
+        val = SyntheticEvalLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes, 2,
+                                  trainer.device)
     crit = nn.CrossEntropyLoss()
     trainer.train(loader, val, start_epoch=start_epoch,
                   evaluate_fn=lambda m, l: evaluate_model(m, l, crit, num_classes=config.model.num_classes))
