@@ -71,8 +71,10 @@ def test_evaluate_model_matches_a_plain_evaluation():
             n += len(b["label"])
     assert abs(got["val_acc"] - 100.0 * hits1 / n) < 1e-9 and abs(got["val_acc_top5"] - 100.0 * hits5 / n) < 1e-9
     assert abs(got["loss"] - loss / n) < 1e-4 * abs(loss / n)
-    sub = evaluate_model(model, batches[:1], crit, num_classes=10, valid_indices=[1, 3, 5, 7])
-    assert 0.0 <= sub["val_acc"] <= 100.0 and sub["val_acc_top5"] == 100.0        # 4 classes: top-5 always hits ... if
+    # a class subset (ImageNet-R style): labels index the SUBSET's columns; with 4 columns top-5 always hits
+    sub_batch = [{"pixel_values": batches[0]["pixel_values"], "label": batches[0]["label"] % 4}]
+    sub = evaluate_model(model, sub_batch, crit, num_classes=4, valid_indices=[1, 3, 5, 7])
+    assert 0.0 <= sub["val_acc"] <= 100.0 and sub["val_acc_top5"] == 100.0
     eff = measure_efficiency(model, image_size=32, batch_size=16, num_warmup=2, num_batches=5)
     assert all(v == v and v > 0 for v in eff.values()), eff
 

@@ -86,24 +86,20 @@ def test_pipeline_is_given_up_when_no_batch_is_ever_announced():
     trainer.check_health()
 
 
-def test_c1_step_matches_the_cpu_oracle_step():
-    """One BASELINE-c1-size step (DeiT-T / ViT-S, 32x32, patch 4) on the HIP path against the CPU restatement of the
-    whole step (oracle/cpu_step.py: plain fp32 torch ViTs + the oracle loss pinned to the reference) on IDENTICAL
-    weights, projections and images: ranks exact, mixing weights, loss terms, and the gradient of every student
-    parameter.  The GPU path runs bf16 activations (the CPU one fp32), which sets the tolerances: loss terms 1 %
-    (measured 6e-4), flat gradient: norm within 1 % (measured 1e-3), cosine > 0.998."""
+def _step_vs_oracle(trainer, batch, student, teacher_name, img, patch, classes, rank_slack):
     from basd_amd.models.vit import create_vit
     from oracle.cpu_step import reference_loss_backward
-    trainer, batch = _make(32)
     teacher = trainer._teacher
     sel = trainer.basd_loss.layer_selector
     with torch.no_grad():
         sel.log_temperatures.add_(torch.linspace(-0.3, 0.3, 4, device="cuda"))
     # ---- CPU copies (fp32) of exactly the weights the GPU path uses
-    s_cpu = create_vit("deit_tiny_patch16_224", num_classes=100, img_size=32, patch_size=4).train()
+    t_patch = teacher.model.patch_embed.patch_size
+    s_cpu = create_vit(student, num_classes=classes, img_size=img, patch_size=patch).train()
     s_cpu.load_state_dict({k: v.detach().float().cpu() for k, v in trainer.model.state_dict().items()})
-    t_cpu = create_vit("vit_small_patch16_224", num_classes=0, img_size=32, patch_size=4).eval()
-    t_cpu.load_state_dict({k: v.detach().float().cpu() for k, v in teacher.model.state_dict().items()})
+    t_cpu = create_vit(teacher_name, num_classes=0, img_size=img, patch_size=t_patch).eval()
+    t_cpu.load_state_dict({k: v.detach().float().cpu() for k, v in teacher.model.state_dict().items()
+                           if not k.startswith("head.")}, strict=False)
     log_t = sel.log_temperatures.detach().cpu().clone().requires_grad_(True)
     targets = batch["label"].cpu()
     want = reference_loss_backward(s_cpu, t_cpu, batch["clean"].cpu(), batch["augmented"].cpu(), targets,
@@ -114,9 +110,10 @@ def test_c1_step_matches_the_cpu_oracle_step():
     torch.cuda.synchronize()
     from basd_amd.losses._ops import get_ops
     get_ops().check_status()
-    # bf16 tokens on one side, fp32 on the other: with a random-init teacher on noise images the MP threshold sits
-    # inside the dense noise bulk (ranks ~70 of 192), so a rank may move by one or two across the two precisions
-    assert max(abs(a - b) for a, b in zip(sel.subspace_ranks.values(), want["ranks"].tolist())) <= 2
+    ranks_gpu, ranks_cpu = list(sel.subspace_ranks.values()), want["ranks"].tolist()
+    # bf16 tokens on one side, fp32 on the other: a rank may move where the MP threshold sits inside a dense part of
+    # the spectrum (random-init teacher on noise: c1); on structured images it is exact or off by one
+    assert max(abs(a - b) for a, b in zip(ranks_gpu, ranks_cpu)) <= rank_slack, (ranks_gpu, ranks_cpu)
     torch.testing.assert_close(sel.last_weights.cpu(), want["weights"].detach(), atol=5e-3, rtol=0)
     torch.testing.assert_close(trainer.basd_loss.last_terms["geo"].cpu(), want["geo"].detach(), rtol=1e-2, atol=0)
     torch.testing.assert_close(trainer.basd_loss.last_terms["ce"].cpu(), want["ce"].detach(), rtol=1e-2, atol=0)
@@ -128,12 +125,35 @@ def test_c1_step_matches_the_cpu_oracle_step():
         ref.append(cpu_params[name].grad.flatten())
     got, ref = torch.cat(got).double(), torch.cat(ref).double()
     cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
-    print(f"step-level: loss {float(loss):.5f} vs {float(want['loss']):.5f}; |g| {float(got.norm()):.4e} vs "
-          f"{float(ref.norm()):.4e}; cosine {cos:.5f}")
+    print(f"step-level {student} / {teacher_name}: loss {float(loss):.5f} vs {float(want['loss']):.5f}; |g| "
+          f"{float(got.norm()):.4e} vs {float(ref.norm()):.4e}; cosine {cos:.5f}; ranks {ranks_gpu} vs {ranks_cpu}")
     assert abs(float(got.norm()) - float(ref.norm())) <= 1e-2 * float(ref.norm())     # measured 1e-3
     assert cos > 0.998
     g_t = sel.log_temperatures.grad.detach().cpu()
     torch.testing.assert_close(g_t, log_t.grad, rtol=5e-2, atol=1e-6)
+
+
+def test_c1_step_matches_the_cpu_oracle_step():
+    """One BASELINE-c1-size step (DeiT-T / ViT-S, 32x32, patch 4) on the HIP path against the CPU restatement of the
+    whole step (oracle/cpu_step.py: plain fp32 torch ViTs + the oracle loss pinned to the reference) on IDENTICAL
+    weights, projections and images: ranks, mixing weights, loss terms, and the gradient of every student parameter.
+    The GPU path runs bf16 activations (the CPU one fp32), which sets the tolerances: loss terms 1 % (measured 6e-4),
+    flat gradient: norm within 1 % (measured 1e-3), cosine > 0.998."""
+    trainer, batch = _make(32)
+    _step_vs_oracle(trainer, batch, "deit_tiny_patch16_224", "vit_small_patch16_224", 32, 4, 100, rank_slack=2)
+
+
+@pytest.mark.parametrize("student,teacher,batch,slack", [("deit_tiny_patch16_224", "vit_base_patch16_224", 8, 1),
+                                                         ("deit_small_patch16_224", "vit_large_patch16_224", 4, 1),
+                                                         ("vit_base_patch16_224", "vit_huge_patch14_224", 4, 2)])
+def test_model_shape_steps_match_the_cpu_oracle_step(student, teacher, batch, slack):
+    """The same whole-step comparison at the MODEL shapes of BASELINE configs[1], [3] and [4] (224 x 224 images, small
+    batches so that the fp32 CPU step stays in tens of seconds): DeiT-T / ViT-B, DeiT-S / ViT-L, ViT-B / ViT-H (head
+    dim 80, 257 tokens, 256 -> 196 token resampling).  Reference step: src/training/trainer.py:133-159."""
+    trainer, b = _make_preset(student, teacher, batch)
+    # ranks: exact or off by one at c2 / c4 (measured: 1 of 12, 5 of 24 layers off by one); at c5 the 784 token rows
+    # barely exceed the 768 columns, the spectrum is dense around the threshold (ranks ~230) and one layer moves by 2
+    _step_vs_oracle(trainer, b, student, teacher, 224, 16, 1000, rank_slack=slack)
 
 
 def test_non_finite_input_raises_a_linalg_error_at_most_two_steps_late():
