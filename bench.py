@@ -162,6 +162,8 @@ def main():
 
     t_start = time.perf_counter()
     trainer, info = build(cfg, device=dev)
+    from basd_amd.losses import _ops as basd_ops
+    basd_ops.FALLBACKS.clear()          # the start-up probes (one dummy image through each model, fp32) do not count
     progress(f"built {args.config}: {student_preset} / {teacher_preset}, {args.batch} images per GPU")
     # four different synthetic batches, cycled through the warm-up and timed steps: no step sees the data of the
     # previous one (nothing could be reused across steps, and the data-dependent Jacobi sweep counts vary); the

@@ -124,6 +124,32 @@ def test_token_gram(nat, rows, d_in, d_out, dtype):
     assert torch.allclose(gram, gram.T, rtol=0, atol=1e-12 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("rows,d_in,d_out", [(50176, 768, 192), (3000, 384, 192), (1000, 64, 32)])
+def test_token_gram_centred_statistics_survive_a_dominant_mean(nat, rows, d_in, d_out):
+    """bf16 tokens whose column means are 30 x their spread (a structured data set; block outputs of a ViT carry such
+    offsets): the CENTRED Gram the selector forms as unc - s s^T / m (layer_selector.py:35) must keep fp32-level
+    accuracy relative to ITSELF, not relative to the 900 x larger uncentred Gram -- the kernel centres every 128-row
+    tile on its own mean before the fp32 MFMA and carries the means in fp64."""
+    g = torch.Generator().manual_seed(rows + d_out)
+    x = (torch.randn(rows, d_in, generator=g) + 30.0 * torch.randn(1, d_in, generator=g)).bfloat16()
+    p = torch.linalg.qr(torch.randn(d_in, d_out, generator=g))[0].T.contiguous()
+    gram, colsum = nat.token_gram(x.cuda(), p.cuda())
+    z = x.double() @ p.double().T
+    ref_unc, ref_sum = z.T @ z, z.sum(0)
+    ref_cen = ref_unc - torch.outer(ref_sum, ref_sum) / rows
+    cen = gram.cpu() - torch.outer(colsum.cpu(), colsum.cpu()) / rows
+    assert torch.allclose(gram.cpu(), ref_unc, rtol=0, atol=1e-6 * float(ref_unc.abs().max()))
+    assert torch.allclose(colsum.cpu(), ref_sum, rtol=0, atol=1e-6 * float(ref_sum.abs().max()))
+    assert float(ref_unc.abs().max()) > 100 * float(ref_cen.abs().max())          # the regime this test is about
+    # what is left is the fp32 accumulation of z = x P^T itself (values ~30, 768 terms: ~5e-5 absolute per entry, summed
+    # over 50 176 rows against centred partners of unit spread); an fp32 Gram of the uncentred z would be off by 1e-3
+    err = float((cen - ref_cen).abs().max()) / float(ref_cen.abs().max())
+    assert err < 2e-5, err
+    ev, ev_ref = torch.linalg.eigvalsh(cen), torch.linalg.eigvalsh(ref_cen)
+    assert float(ev.min()) > 0.5 * float(ev_ref.min()) > 0
+    assert torch.allclose(ev, ev_ref, rtol=0, atol=2e-5 * float(ev_ref.max()))
+
+
 def test_mp_rank_matches_oracle(nat):
     from oracle import basd_oracle as O
     g = torch.Generator().manual_seed(0)

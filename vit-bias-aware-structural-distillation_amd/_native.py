@@ -590,18 +590,21 @@ def transpose_table(master: torch.Tensor, out: torch.Tensor, table) -> None:
 
 def bgemm_f64(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
               out_dtype=torch.float64, symmetric: bool = False) -> torch.Tensor:
-    """Batched op(a) @ op(b) with fp64 accumulation; a, b [batch, r, c] fp32/fp64 contiguous."""
+    """Batched op(a) @ op(b) with fp64 accumulation; a, b [batch, r, c] fp32/fp64 contiguous.  An operand with batch
+    1 is broadcast over the other one's batch (batch stride 0: no copies)."""
     _need_cuda(a, b)
     a, b = a.contiguous(), b.contiguous()
     code = {torch.float32: DTYPE_F32, torch.float64: DTYPE_F64}
-    batch = a.shape[0]
+    batch = max(a.shape[0], b.shape[0])
     M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
     K2, N = (b.shape[2], b.shape[1]) if trans_b else (b.shape[1], b.shape[2])
-    assert K == K2 and b.shape[0] == batch, (a.shape, b.shape, trans_a, trans_b)
+    assert K == K2 and a.shape[0] in (1, batch) and b.shape[0] in (1, batch), (a.shape, b.shape, trans_a, trans_b)
     c = torch.empty(batch, M, N, dtype=out_dtype, device=a.device)
     i64 = ctypes.c_int64
-    _check(lib().basd_bgemm_f64(_ptr(a), code[a.dtype], i64(a.shape[1] * a.shape[2]), a.shape[2], int(trans_a),
-                                _ptr(b), code[b.dtype], i64(b.shape[1] * b.shape[2]), b.shape[2], int(trans_b),
+    sa = a.shape[1] * a.shape[2] if a.shape[0] == batch else 0
+    sb = b.shape[1] * b.shape[2] if b.shape[0] == batch else 0
+    _check(lib().basd_bgemm_f64(_ptr(a), code[a.dtype], i64(sa), a.shape[2], int(trans_a),
+                                _ptr(b), code[b.dtype], i64(sb), b.shape[2], int(trans_b),
                                 _ptr(c), code[out_dtype], i64(M * N), N, batch, M, N, K, int(symmetric), _stream()),
            "basd_bgemm_f64")
     return c

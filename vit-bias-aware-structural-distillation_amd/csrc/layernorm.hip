@@ -55,7 +55,10 @@ __device__ __forceinline__ float group_allsum(float v) {
 }
 
 // FUSE_ADD: s = bf16(x + res) is written to `sum_out` and normalised; otherwise x is normalised.
-template <int G, int NCH, bool FUSE_ADD>
+// U rows per group are in flight at a time (all their loads are issued before the first reduction): with one row per
+// group and iteration a CU holds ~18 KB of loads in flight and the narrow student rows (D = 192: 384 bytes) ran at
+// 2.0 - 2.7 TB/s.
+template <int G, int NCH, bool FUSE_ADD, int U>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x,
                                                      const unsigned short* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -79,17 +82,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
   }
   const float inv_d = 1.f / (float)D;
   const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t r = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub; r < rows; r += wstride) {
-    float f[NCH][8];
-    float s = 0.f;
+  // a lane leaves the loop when its FIRST row is out of range; rows u > 0 beyond the end are skipped lane by lane (the
+  // cross-lane reductions only combine lanes of the same row group, which agree on r)
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub; r0 < rows; r0 += wstride * U) {
+    uint4 xv[U][NCH], rv[U][NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lg + c * G;
-      if (ch < nchunk) {
-        unpack8(*reinterpret_cast<const uint4*>(x + r * D + ch * 8), f[c]);
-        if (FUSE_ADD) {
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * wstride;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lg + c * G;
+        xv[u][c] = make_uint4(0, 0, 0, 0);
+        rv[u][c] = make_uint4(0, 0, 0, 0);
+        if (ch < nchunk && r < rows) {
+          xv[u][c] = *reinterpret_cast<const uint4*>(x + r * D + ch * 8);
+          if (FUSE_ADD) rv[u][c] = *reinterpret_cast<const uint4*>(res + r * D + ch * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * wstride;
+      const bool live = r < rows;
+      float f[NCH][8];
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lg + c * G;
+        unpack8(xv[u][c], f[c]);
+        if (FUSE_ADD && ch < nchunk && live) {
           float fr[8];
-          unpack8(*reinterpret_cast<const uint4*>(res + r * D + ch * 8), fr);
+          unpack8(rv[u][c], fr);
           // stochastic depth of a trained block: the branch x is scaled per SAMPLE (keep mask / keep probability)
           const float sc = row_scale ? row_scale[r / rows_per_scale] : 1.f;
 #pragma unroll
@@ -98,43 +121,40 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
           o.x = pack2(f[c][0], f[c][1]); o.y = pack2(f[c][2], f[c][3]); o.z = pack2(f[c][4], f[c][5]); o.w = pack2(f[c][6], f[c][7]);
           *reinterpret_cast<uint4*>(sum_out + r * D + ch * 8) = o;
         }
-      } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[c][i] = 0.f;
+        for (int i = 0; i < 8; ++i) s += f[c][i];
       }
+      const float mu = group_allsum<G>(s) * inv_d;
+      float q = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += f[c][i];
-    }
-    // rows beyond `rows` never enter the loop, but the lanes of the other row group of this wave may
-    // have left it: the cross-lane reductions below only combine lanes of the SAME group
-    const float mu = group_allsum<G>(s) * inv_d;
-    float q = 0.f;
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lg + c * G;
+        if (ch < nchunk) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lg + c * G;
-      if (ch < nchunk) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = f[c][i] - mu; q = fmaf(d, d, q); }   // two-pass variance
+          for (int i = 0; i < 8; ++i) { const float d = f[c][i] - mu; q = fmaf(d, d, q); }   // two-pass variance
+        }
       }
-    }
-    const float rs = rsqrtf(group_allsum<G>(q) * inv_d + eps);
+      const float rs = rsqrtf(group_allsum<G>(q) * inv_d + eps);
+      if (live) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lg + c * G;
-      if (ch < nchunk) {
-        float o[8];
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = lg + c * G;
+          if (ch < nchunk) {
+            float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = fmaf((f[c][i] - mu) * rs, g[c][i], b[c][i]);
-        uint4 out;
-        out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
-        *reinterpret_cast<uint4*>(y + r * D + ch * 8) = out;
+            for (int i = 0; i < 8; ++i) o[i] = fmaf((f[c][i] - mu) * rs, g[c][i], b[c][i]);
+            uint4 out;
+            out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+            *reinterpret_cast<uint4*>(y + r * D + ch * 8) = out;
+          }
+        }
+        if (lg == 0 && mean != nullptr) { mean[r] = mu; rstd[r] = rs; }
       }
     }
-    if (lg == 0 && mean != nullptr) { mean[r] = mu; rstd[r] = rs; }
   }
 }
 
-template <int G, int NCH>
+template <int G, int NCH, int U>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int64_t rows, int D,
@@ -156,53 +176,82 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
   }
   const float inv_d = 1.f / (float)D;
   const int64_t wstride = (int64_t)gridDim.x * 4 * RPW;
-  for (int64_t r = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub; r < rows; r += wstride) {
-    const float mu = mean[r], rs = rstd[r];
-    float xh[NCH][8], gg[NCH][8];
-    float s1 = 0.f, s2 = 0.f;
+  // U rows per group in flight (see ln_fwd_kernel)
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub; r0 < rows; r0 += wstride * U) {
+    uint4 xv[U][NCH], yv[U][NCH], rv[U][NCH];
+    float mus[U], rss[U];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lg + c * G;
-      if (ch < nchunk) {
-        float fx[8], fdy[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + r * D + ch * 8), fx);
-        unpack8(*reinterpret_cast<const uint4*>(dy + r * D + ch * 8), fdy);
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * wstride;
+      const bool live = r < rows;
+      mus[u] = live ? mean[r] : 0.f;
+      rss[u] = live ? rstd[r] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          xh[c][i] = (fx[i] - mu) * rs;
-          gg[c][i] = fdy[i] * g[c][i];
-          s1 += gg[c][i];
-          s2 = fmaf(gg[c][i], xh[c][i], s2);
-          dg[c][i] = fmaf(fdy[i], xh[c][i], dg[c][i]);
-          db[c][i] += fdy[i];
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lg + c * G;
+        xv[u][c] = make_uint4(0, 0, 0, 0);
+        yv[u][c] = make_uint4(0, 0, 0, 0);
+        rv[u][c] = make_uint4(0, 0, 0, 0);
+        if (ch < nchunk && live) {
+          xv[u][c] = *reinterpret_cast<const uint4*>(x + r * D + ch * 8);
+          yv[u][c] = *reinterpret_cast<const uint4*>(dy + r * D + ch * 8);
+          if (dres != nullptr) rv[u][c] = *reinterpret_cast<const uint4*>(dres + r * D + ch * 8);
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { xh[c][i] = 0.f; gg[c][i] = 0.f; }
       }
     }
-    const float m1 = group_allsum<G>(s1) * inv_d, m2 = group_allsum<G>(s2) * inv_d;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = lg + c * G;
-      if (ch < nchunk) {
-        float o[8];
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * wstride;
+      const bool live = r < rows;
+      const float mu = mus[u], rs = rss[u];
+      float xh[NCH][8], gg[NCH][8];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = rs * (gg[c][i] - m1 - xh[c][i] * m2);
-        if (dres != nullptr) {                      // gradient arriving through the residual path of a pre-norm block
-          float fr[8];
-          unpack8(*reinterpret_cast<const uint4*>(dres + r * D + ch * 8), fr);
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lg + c * G;
+        if (ch < nchunk && live) {
+          float fx[8], fdy[8];
+          unpack8(xv[u][c], fx);
+          unpack8(yv[u][c], fdy);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] += fr[i];
+          for (int i = 0; i < 8; ++i) {
+            xh[c][i] = (fx[i] - mu) * rs;
+            gg[c][i] = fdy[i] * g[c][i];
+            s1 += gg[c][i];
+            s2 = fmaf(gg[c][i], xh[c][i], s2);
+            dg[c][i] = fmaf(fdy[i], xh[c][i], dg[c][i]);
+            db[c][i] += fdy[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { xh[c][i] = 0.f; gg[c][i] = 0.f; }
         }
-        uint4 out;
-        out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
-        *reinterpret_cast<uint4*>(dx + r * D + ch * 8) = out;
-        if (dbranch != nullptr) {                   // gradient of the (stochastic-depth scaled) branch input
-          const float sc = row_scale ? row_scale[r / rows_per_scale] : 1.f;
-          out.x = pack2(sc * o[0], sc * o[1]); out.y = pack2(sc * o[2], sc * o[3]);
-          out.z = pack2(sc * o[4], sc * o[5]); out.w = pack2(sc * o[6], sc * o[7]);
-          *reinterpret_cast<uint4*>(dbranch + r * D + ch * 8) = out;
+      }
+      const float m1 = group_allsum<G>(s1) * inv_d, m2 = group_allsum<G>(s2) * inv_d;
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = lg + c * G;
+          if (ch < nchunk) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = rs * (gg[c][i] - m1 - xh[c][i] * m2);
+            if (dres != nullptr) {                      // gradient arriving through the residual path of a pre-norm block
+              float fr[8];
+              unpack8(rv[u][c], fr);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) o[i] += fr[i];
+            }
+            uint4 out;
+            out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]); out.z = pack2(o[4], o[5]); out.w = pack2(o[6], o[7]);
+            *reinterpret_cast<uint4*>(dx + r * D + ch * 8) = out;
+            if (dbranch != nullptr) {                   // gradient of the (stochastic-depth scaled) branch input
+              const float sc = row_scale ? row_scale[r / rows_per_scale] : 1.f;
+              out.x = pack2(sc * o[0], sc * o[1]); out.y = pack2(sc * o[2], sc * o[3]);
+              out.z = pack2(sc * o[4], sc * o[5]); out.w = pack2(sc * o[6], sc * o[7]);
+              *reinterpret_cast<uint4*>(dbranch + r * D + ch * 8) = out;
+            }
+          }
         }
       }
     }
@@ -250,14 +299,14 @@ static int launch_ln_fwd(const void* x, const void* res, const float* gamma, con
   const unsigned short* rp = (const unsigned short*)res;
   unsigned short* sp = (unsigned short*)sum_out;
   unsigned short* yp = (unsigned short*)y;
-#define BASD_LN_FWD(G, NCH)                                                                                   \
-  hipLaunchKernelGGL((ln_fwd_kernel<G, NCH, FUSE>), dim3(ln_grid(rows, 4 * (64 / G))), dim3(256), 0, st, xp, rp, \
+#define BASD_LN_FWD(G, NCH, U)                                                                                  \
+  hipLaunchKernelGGL((ln_fwd_kernel<G, NCH, FUSE, U>), dim3(ln_grid(rows, 4 * (64 / G) * U)), dim3(256), 0, st, xp, rp, \
                      gamma, beta, rows, D, eps, sp, yp, mean, rstd, row_scale, rows_per_scale)
-  if (nchunk <= 32) BASD_LN_FWD(32, 1);
-  else if (nchunk <= 64) BASD_LN_FWD(64, 1);
-  else if (nchunk <= 128) BASD_LN_FWD(64, 2);
-  else if (nchunk <= 192) BASD_LN_FWD(64, 3);
-  else BASD_LN_FWD(64, 4);
+  if (nchunk <= 32) BASD_LN_FWD(32, 1, 4);
+  else if (nchunk <= 64) BASD_LN_FWD(64, 1, 4);
+  else if (nchunk <= 128) BASD_LN_FWD(64, 2, 2);
+  else if (nchunk <= 192) BASD_LN_FWD(64, 3, 1);
+  else BASD_LN_FWD(64, 4, 1);
 #undef BASD_LN_FWD
   return check_launch(FUSE ? "add_layernorm_fwd_bf16" : "layernorm_fwd_bf16");
 }
@@ -298,16 +347,16 @@ extern "C" int basd_layernorm_bwd_bf16(const void* dy, const void* x, const floa
   // every workgroup ends with one fp32 atomic per column into the same 2 D addresses, which the memory side
   // serialises (~20 ns per workgroup, measured): 512 workgroups balance that tail against load parallelism
   const int bwd_cap = 512;
-#define BASD_LN_BWD(G, NCH)                                                                                       \
-  hipLaunchKernelGGL((ln_bwd_kernel<G, NCH>), dim3(ln_grid(rows, 4 * (64 / G) * 4, bwd_cap)), dim3(256), lds, st,   \
+#define BASD_LN_BWD(G, NCH, U)                                                                                    \
+  hipLaunchKernelGGL((ln_bwd_kernel<G, NCH, U>), dim3(ln_grid(rows, 4 * (64 / G) * 4, bwd_cap)), dim3(256), lds, st, \
                      (const unsigned short*)dy, (const unsigned short*)x, gamma, mean, rstd, rows, D,               \
                      (unsigned short*)dx, dgamma, dbeta, (const unsigned short*)dres, (unsigned short*)dbranch,      \
                      row_scale, rows_per_scale < 1 ? 1 : rows_per_scale)
-  if (nchunk <= 32) BASD_LN_BWD(32, 1);
-  else if (nchunk <= 64) BASD_LN_BWD(64, 1);
-  else if (nchunk <= 128) BASD_LN_BWD(64, 2);
-  else if (nchunk <= 192) BASD_LN_BWD(64, 3);
-  else BASD_LN_BWD(64, 4);
+  if (nchunk <= 32) BASD_LN_BWD(32, 1, 4);
+  else if (nchunk <= 64) BASD_LN_BWD(64, 1, 4);
+  else if (nchunk <= 128) BASD_LN_BWD(64, 2, 2);
+  else if (nchunk <= 192) BASD_LN_BWD(64, 3, 1);
+  else BASD_LN_BWD(64, 4, 1);
 #undef BASD_LN_BWD
   return check_launch("layernorm_bwd_bf16");
 }

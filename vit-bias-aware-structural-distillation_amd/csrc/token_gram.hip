@@ -301,21 +301,63 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
         for (int reg = 0; reg < 4; ++reg)
           Z[(wave * 32 + g * 16 + (lane >> 4) * 4 + reg) * LDZ + c * 16 + (lane & 15)] = zacc[g][c][reg];
     __syncthreads();
+    // ---- Gram of the tile.  With s = the tile's exact column sums (fp64), n its rows and mu ANY fp32 vector,
+    //     sum_rows z z^T = G_c + mu w^T + w mu^T,   G_c = sum (z - mu)(z - mu)^T,   w = s - (n / 2) mu.
+    // mu = the fp32-rounded column mean keeps the entries of z - mu small (and the subtraction exact): G_c runs on the
+    // fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 sums over 128 rows), the two rank-1 terms are
+    // one fp64 MFMA per Gram tile, everything is added up in fp64.  The caller forms the centred Gram as unc - s s^T / m:
+    // with an fp32 Gram of the UNcentred tokens that subtraction cancels the leading digits whenever the token mean
+    // dominates their spread; the all-fp64 Gram before it ran at half the MFMA rate and made this phase (41 k cycles per
+    // tile) longer than the three-split projection (28 k).
+    const int64_t rows_left = rows - tile * TM2;
+    const int nvalid = rows_left < TM2 ? (int)rows_left : TM2;
+    float* mu = Z + (size_t)TM2 * LDZ;                     // [D_OUT] fp32 tile mean (behind the z tile)
+    double* wv = reinterpret_cast<double*>(mu + D_OUT);    // [D_OUT] fp64 w
     if (tid < D_OUT) {
-      double s = 0.0;
-      for (int r = 0; r < TM2; ++r) s += (double)Z[r * LDZ + tid];
-      csum += s;
+      double sacc = 0.0;
+      for (int r = 0; r < TM2; ++r) sacc += (double)Z[r * LDZ + tid];      // rows beyond `rows` are zeros
+      const float m_ = (float)(sacc / (double)nvalid);
+      mu[tid] = m_;
+      wv[tid] = sacc - 0.5 * (double)nvalid * (double)m_;
+      csum += sacc;
     }
+    __syncthreads();
+    for (int e = tid; e < nvalid * D_OUT; e += 256) {
+      const int r = e / D_OUT, c = e - r * D_OUT;
+      Z[r * LDZ + c] -= mu[c];
+    }
+    __syncthreads();
 #pragma unroll
     for (int gi = 0; gi < GT_PER_WAVE; ++gi) {
       const int g = wave + gi * 4;
       if (g < NGT) {
         const int it = s_it[g], jt = s_jt[g];
-#pragma unroll 4
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
         for (int kk = 0; kk < TM2 / 4; ++kk) {
           const float* zr = Z + (kk * 4 + (lane >> 4)) * LDZ + (lane & 15);
-          gacc[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)zr[it * 16], (double)zr[jt * 16], gacc[gi], 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[it * 16], zr[jt * 16], t, 0, 0, 0);
         }
+        // the fp32 tile holds rows 4 q + reg (q = lane >> 4), the fp64 accumulator rows q + 4 reg: a 4 x 4 transpose
+        // between lane group and register -- two register <-> lane butterflies
+        {
+          typedef unsigned int tg_u32x2 __attribute__((ext_vector_type(2)));
+          tg_u32x2 a02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[0]), __float_as_uint(t[2]), false, false);
+          tg_u32x2 a13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[1]), __float_as_uint(t[3]), false, false);
+          tg_u32x2 b01 = __builtin_amdgcn_permlane16_swap(a02[0], a13[0], false, false);
+          tg_u32x2 b23 = __builtin_amdgcn_permlane16_swap(a02[1], a13[1], false, false);
+          gacc[gi][0] += (double)__uint_as_float(b01[0]);
+          gacc[gi][1] += (double)__uint_as_float(b01[1]);
+          gacc[gi][2] += (double)__uint_as_float(b23[0]);
+          gacc[gi][3] += (double)__uint_as_float(b23[1]);
+        }
+        // + mu w^T + w mu^T: k slot 0 carries (mu_i, w_j), k slot 1 (w_i, mu_j), the other two are zero
+        const int ks = lane >> 4;
+        const double mi = (double)mu[it * 16 + (lane & 15)], mj = (double)mu[jt * 16 + (lane & 15)];
+        const double wi = wv[it * 16 + (lane & 15)], wj = wv[jt * 16 + (lane & 15)];
+        const double ai = ks == 0 ? mi : ks == 1 ? wi : 0.0;
+        const double bj = ks == 0 ? wj : ks == 1 ? mj : 0.0;
+        gacc[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bj, gacc[gi], 0, 0, 0);
       }
     }
   }
@@ -341,7 +383,7 @@ static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, int rows_per
                              const void* psplit, double* gram, double* colsum, hipStream_t st) {
   constexpr int D_OUT = NCT * 16;
   const size_t p_bytes = (size_t)2 * 3 * D_OUT * PROW;      // double-buffered P chunk
-  const size_t z_bytes = (size_t)TM2 * (D_OUT + 16) * 4;
+  const size_t z_bytes = (size_t)TM2 * (D_OUT + 16) * 4 + (size_t)D_OUT * 12;     // z tile + fp32 mean + fp64 w
   const size_t lds = p_bytes > z_bytes ? p_bytes : z_bytes;
   const int64_t ntiles = (rows + TM2 - 1) / TM2;
   const int grid = (int)(ntiles < 256 ? ntiles : 256);

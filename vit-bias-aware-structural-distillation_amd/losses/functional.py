@@ -24,7 +24,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from ._ops import get_ops
+from ._ops import get_ops, note_library_gemm
 
 _EPS32 = float(torch.finfo(torch.float32).eps)
 PCHOL_TOL = 1e-13
@@ -359,7 +359,10 @@ class _SelectorWeightsFn(torch.autograd.Function):
             ready()           # join the stream that produced the teacher frames only now: the student's own
                               # (latency-bound, 8-workgroup) eigen-solve above overlaps the teacher's
 
-        a_full = torch.einsum("ibd,jcd->ijbc", v_s, vm_t)           # [E, L, D(b), D(c)]
+        # every product of the selector (forward seeds and backward) runs on the own batched fp64-accumulated GEMM
+        # (basd_bgemm_f64; an operand with batch 1 is broadcast): no library GEMM in the selector path
+        a_full = torch.stack([ops.bgemm_f64(v_s[i:i + 1], vm_t, trans_b=True, out_dtype=torch.float32)
+                              for i in range(E)])                   # [E, L, D(b), D(c)] = V_s[i]^T-rows . V_t[j]-rows
         a_bar = a_full * keep.view(1, L, D, 1)                      # rows b < k_j
 
         if D <= WIDE_PANEL:
@@ -385,8 +388,10 @@ class _SelectorWeightsFn(torch.autograd.Function):
 
         # seeds of the backward, per unit d(d2_ij): Phi = U diag(gsig / sig) U^T = vec^T diag(coef) vec,
         # T = A_full A_bar^T Phi
-        phi = torch.matmul((vec * coef.unsqueeze(-1)).transpose(-1, -2), vec)         # [E, L, b, c]
-        t_seed = a_full @ a_bar.transpose(-1, -2) @ phi              # [E, L, D(b), D(a)]
+        vec_f = vec.reshape(E * L, D, D).float()
+        phi = ops.bgemm_f64(vec_f * coef.reshape(E * L, D, 1), vec_f, trans_a=True, out_dtype=torch.float32)   # [E L, b, c]
+        af, ab = a_full.reshape(E * L, D, D), a_bar.reshape(E * L, D, D)
+        t_seed = ops.bgemm_f64(ops.bgemm_f64(af, ab, trans_b=True), phi, out_dtype=torch.float32).view(E, L, D, D)
         t_seed = t_seed * (1.0 - keep).view(1, L, D, 1)              # only b >= k_j (cross-subspace terms)
 
         ctx.save_for_backward(log_temp, proj_s, wts, d2, tau, t_seed, v_s, lam_s, *student)
@@ -408,16 +413,18 @@ class _SelectorWeightsFn(torch.autograd.Function):
         gap = lam_s.unsqueeze(1) - lam_s.unsqueeze(2)                            # [E, b, a] = lam_a - lam_b
         k = torch.where(gap.abs() > 0, c / torch.where(gap.abs() > 0, gap, torch.ones_like(gap)),
                         torch.zeros_like(c))
-        v64 = v_s.double()
-        g_gram = v64.transpose(1, 2) @ k @ v64                                   # [E, D, D]
-        p64 = proj_s.double()
-        w_tok = (p64.t() @ (g_gram + g_gram.transpose(1, 2)) @ p64).float()      # [E, D_s, D_s]
+        ops = get_ops()
+        v32 = v_s.float()
+        g_gram = ops.bgemm_f64(ops.bgemm_f64(v32, k, trans_a=True), v32)         # V^T K V  [E, D, D] fp64
+        g_sym = g_gram + g_gram.transpose(1, 2)
+        p32 = proj_s.float().unsqueeze(0)                                        # [1, D, D_s], broadcast over E
+        w_tok = ops.bgemm_f64(ops.bgemm_f64(p32, g_sym, trans_a=True), p32, out_dtype=torch.float32)   # P^T G P [E, D_s, D_s]
         grads = []
         for i in range(E):
             s = student[i]
             # centring z = s P^T over rows == centring s (linear map), so d loss / d s = (s - mean) W
-            centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
-            grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
+            centred = (s.float() - s.float().mean(dim=(0, 1), keepdim=True)).reshape(1, -1, s.shape[-1])
+            grads.append(ops.bgemm_f64(centred, w_tok[i:i + 1], out_dtype=torch.float32).reshape(s.shape).to(s.dtype))
         return (g_lt, None, None, None, None, None, None, None, *grads)
 
 
@@ -498,6 +505,10 @@ class _ProcrustesFn(torch.autograd.Function):
         gl = g_loss.float().reshape(-1).contiguous()
         # residuals R = W - (other side) G^T, their scaling by 2 gl sqrt(a) and the row dots <R, W> that
         # make up d loss / d a: one fused pass per side over the GEMM result
+        # the ONE declared library GEMM of the loss: a batched fp32 product of E B matrices [N, N] x [N, D_t] (60 GF at
+        # c2: 0.62 ms on the library's fp32-MFMA kernel; the own fp64-accumulated batched GEMM needs 1.3 ms, an own
+        # fp32-MFMA version measured 1.05 ms in round 2)
+        note_library_gemm("Procrustes backward: fp32 bmm (A_t t_w)")
         if ctx.token_side:
             p_s, p_t = polar[0] @ s_w, polar[1] @ t_w                # t_w G^T = A_s s_w, s_w G = A_t t_w
         else:
