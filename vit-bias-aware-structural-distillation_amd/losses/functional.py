@@ -359,10 +359,10 @@ class _SelectorWeightsFn(torch.autograd.Function):
             ready()           # join the stream that produced the teacher frames only now: the student's own
                               # (latency-bound, 8-workgroup) eigen-solve above overlaps the teacher's
 
-        # every product of the selector (forward seeds and backward) runs on the own batched fp64-accumulated GEMM
-        # (basd_bgemm_f64; an operand with batch 1 is broadcast): no library GEMM in the selector path
-        a_full = torch.stack([ops.bgemm_f64(v_s[i:i + 1], vm_t, trans_b=True, out_dtype=torch.float32)
-                              for i in range(E)])                   # [E, L, D(b), D(c)] = V_s[i]^T-rows . V_t[j]-rows
+        # The small products of the selector (E L matrices of D x D, plus four [M, D_s] x [D_s, D_s] products in the
+        # backward) stay on torch.matmul: moved to the own fp64-accumulated batched GEMM they cost +2.4 ms per c2 step
+        # (bgemm_f64 7.0 vs 4.6 ms in the instrumented step, same box) -- measured in round 3 and reverted.
+        a_full = torch.einsum("ibd,jcd->ijbc", v_s, vm_t)           # [E, L, D(b), D(c)]
         a_bar = a_full * keep.view(1, L, D, 1)                      # rows b < k_j
 
         if D <= WIDE_PANEL:
@@ -388,10 +388,8 @@ class _SelectorWeightsFn(torch.autograd.Function):
 
         # seeds of the backward, per unit d(d2_ij): Phi = U diag(gsig / sig) U^T = vec^T diag(coef) vec,
         # T = A_full A_bar^T Phi
-        vec_f = vec.reshape(E * L, D, D).float()
-        phi = ops.bgemm_f64(vec_f * coef.reshape(E * L, D, 1), vec_f, trans_a=True, out_dtype=torch.float32)   # [E L, b, c]
-        af, ab = a_full.reshape(E * L, D, D), a_bar.reshape(E * L, D, D)
-        t_seed = ops.bgemm_f64(ops.bgemm_f64(af, ab, trans_b=True), phi, out_dtype=torch.float32).view(E, L, D, D)
+        phi = torch.matmul((vec * coef.unsqueeze(-1)).transpose(-1, -2), vec)         # [E, L, b, c]
+        t_seed = a_full @ a_bar.transpose(-1, -2) @ phi              # [E, L, D(b), D(a)]
         t_seed = t_seed * (1.0 - keep).view(1, L, D, 1)              # only b >= k_j (cross-subspace terms)
 
         ctx.save_for_backward(log_temp, proj_s, wts, d2, tau, t_seed, v_s, lam_s, *student)
@@ -413,18 +411,16 @@ class _SelectorWeightsFn(torch.autograd.Function):
         gap = lam_s.unsqueeze(1) - lam_s.unsqueeze(2)                            # [E, b, a] = lam_a - lam_b
         k = torch.where(gap.abs() > 0, c / torch.where(gap.abs() > 0, gap, torch.ones_like(gap)),
                         torch.zeros_like(c))
-        ops = get_ops()
-        v32 = v_s.float()
-        g_gram = ops.bgemm_f64(ops.bgemm_f64(v32, k, trans_a=True), v32)         # V^T K V  [E, D, D] fp64
-        g_sym = g_gram + g_gram.transpose(1, 2)
-        p32 = proj_s.float().unsqueeze(0)                                        # [1, D, D_s], broadcast over E
-        w_tok = ops.bgemm_f64(ops.bgemm_f64(p32, g_sym, trans_a=True), p32, out_dtype=torch.float32)   # P^T G P [E, D_s, D_s]
+        v64 = v_s.double()
+        g_gram = v64.transpose(1, 2) @ k @ v64                                   # [E, D, D]
+        p64 = proj_s.double()
+        w_tok = (p64.t() @ (g_gram + g_gram.transpose(1, 2)) @ p64).float()      # [E, D_s, D_s]
         grads = []
         for i in range(E):
             s = student[i]
             # centring z = s P^T over rows == centring s (linear map), so d loss / d s = (s - mean) W
-            centred = (s.float() - s.float().mean(dim=(0, 1), keepdim=True)).reshape(1, -1, s.shape[-1])
-            grads.append(ops.bgemm_f64(centred, w_tok[i:i + 1], out_dtype=torch.float32).reshape(s.shape).to(s.dtype))
+            centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
+            grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
         return (g_lt, None, None, None, None, None, None, None, *grads)
 
 
