@@ -481,7 +481,10 @@ __device__ __forceinline__ void gemm_epilogue_direct(gf32x4 (&acc)[4][8], const 
 // cycles per tile.  Also measured and rejected: running XCD x a fraction x / 8 of a tile out of phase (every workgroup
 // parks the tail part of its first tile in a workspace and finishes that tile last): the parking round trip cost more
 // than the smoother stores saved (fc1 305 vs 293 us, proj 90 vs 68).  Non-temporal stores of the output keep it out of
-// the L2 the operands live in (1 - 2 %).
+// the L2 the operands live in (1 - 2 %).  Measured and rejected as well: cutting the tiles of the last, partial round
+// in two along K across pairs of workgroups (2.5 rounds instead of 3 on fc2 / proj): parking both fp32 halves, the drain,
+// the flag and the 512 KB reload cost the finishing workgroup ~20 us -- more than the half tile saves at K = 768 and
+// about what it saves at K = 3072 (fc2 229 vs 224 us, proj 79 vs 69, qkv 194 vs 176).
 // Operand addresses are an SGPR base (tile, K step) + a 32-bit per-lane offset that does not depend on the tile: eight
 // VGPRs instead of sixteen 64-bit pointers, and the next tile costs scalar arithmetic only.
 template <int EPI>
