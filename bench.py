@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU baseline sample (default: the metric's 256 images: one timed CPU step, ~30 s on 16 cores)")
     ap.add_argument("--global-batch", type=int, default=None, help="STRONG scaling: fix the global batch (e.g. 256) and give every rank global / world images; default: weak scaling, --batch images per GPU")
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="further config overrides (A/B "
+                    "experiments, e.g. --set basd.gemm_tile_run=0); the default line uses none")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--no-ab", action="store_true", help="skip the second, unpipelined measurement (profiling runs)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the teacher forward of batch k + 1 with "
@@ -155,7 +157,7 @@ def main():
                                   f"model.student_preset={student_preset}", f"basd.teacher_model_name={teacher_preset}",
                                   f"model.vit.img_size={img_size}", f"model.vit.patch_size={patch}",
                                   f"model.grad_checkpointing={'true' if args.grad_checkpointing else 'false'}"]
-                      + ([f"basd.teacher_patch_size={patch}"] if args.config == "c1" else []))
+                      + ([f"basd.teacher_patch_size={patch}"] if args.config == "c1" else []) + list(args.set))
     def progress(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)

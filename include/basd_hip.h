@@ -26,6 +26,8 @@
  *   basd_gemm_bf16         timm nn.Linear (+ nn.GELU) forward of the ViT blocks, teacher.py:212 / trainer.py:33
  *   basd_gemm_bf16_gelu_fwd, basd_gemm_bf16_gelu_bwd
  *                          timm Mlp (fc1 -> nn.GELU -> fc2) of the TRAINED student: forward and autograd (trainer.py:33,157)
+ *   basd_gemm_bf16x3_f32   the teacher-token projection tokens.reshape(-1, D_t) @ proj_t.T (layer_selector.py:72 / :135)
+ *                          at student widths > 256
  *   basd_transpose_bf16_table
  *                          the W^T operands autograd's nn.Linear backward forms per call (trainer.py:157)
  *   basd_procrustes_fwd    src/losses/relational.py:47-48 (cross-covariance, nuclear norm, U V^T) as one call
@@ -69,6 +71,9 @@ extern "C" {
 #define BASD_STATUS_NONCONVERGED 1   /* a Jacobi solve used all max_sweeps sweeps and was still rotating      */
 #define BASD_STATUS_NONFINITE 2      /* NaN / Inf among the singular values (non-finite input)               */
 #define BASD_STATUS_RANK0 4          /* Marchenko-Pastur rank 0: the reference divides by sum(sw) = 0 here   */
+/* bits 8 .. 27: diagnostics OR-ed in with BASD_STATUS_NONCONVERGED (informational): bits 8-11 the Jacobi kernel variant
+ * (1 LDS-resident, 2 / 3 odd-even with a double / single mailbox, 4 two matrices per workgroup, 5 block ordering),
+ * bits 12-27 the index of the matrix in its launch (saturating at 65535) */
 
 #define BASD_DTYPE_F32 0
 #define BASD_DTYPE_BF16 1
@@ -220,6 +225,12 @@ int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int tr
  * stream; the pipelined BASD step uses 2).  The results do not depend on it. */
 int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
                    int epilogue, int tile_run, void* stream);
+
+/* Teacher-statistics projection z = X P^T at student widths > 256 (src/losses/layer_selector.py:72 / :135: the fixed fp32 projection of
+ * the teacher tokens in front of the subspace SVD): x [M, K] bf16 row-major, w3 [ceil(N / 256) * 256, 3 K] bf16 = the
+ * (hi | mid | lo) bf16 splits of P's rows side by side (zero rows behind N), y [M, N] fp32.  One persistent bf16-MFMA
+ * GEMM of depth 3 K, fp32 accumulation over all three splits.  K % 64 == 0, K >= 128, N % 8 == 0, M > 1792. */
+int basd_gemm_bf16x3_f32(const void* x, const void* w3, float* y, int64_t M, int N, int K, void* stream);
 
 /* The trained student's MLP (timm Mlp: fc1 -> nn.GELU -> fc2, trainer.py:33 / :157) without a separate GELU pass:
  *   fwd:  pre[m][n] = bf16(sum_k x[m][k] w[n][k] + bias[n])   (saved for backward),   y = bf16(gelu(pre))

@@ -150,6 +150,41 @@ def test_token_gram_centred_statistics_survive_a_dominant_mean(nat, rows, d_in, 
     assert torch.allclose(ev, ev_ref, rtol=0, atol=2e-5 * float(ev_ref.max()))
 
 
+@pytest.mark.parametrize("rows,d_in,d_out", [(25216, 1024, 384), (2000, 128, 8), (4133, 192, 264), (65792, 1280, 768)])
+def test_gemm_bf16x3_f32(nat, rows, d_in, d_out):
+    """x P^T with x bf16, P fp32 as one bf16-MFMA GEMM over the three bf16 splits of P: fp32-GEMM accuracy (the splits
+    carry P to 2^-24, the accumulation is fp32), ragged last row block, column tiles wider than the output"""
+    assert nat.gemm_bf16x3_f32_supported(rows, d_out, d_in)
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, d_in, generator=g) * (1 + torch.rand(1, d_in, generator=g))).bfloat16()
+    p = torch.linalg.qr(torch.randn(d_in, max(d_out, 1), generator=g))[0].T.contiguous() if d_out <= d_in else \
+        torch.randn(d_out, d_in, generator=g) / d_in ** 0.5
+    guard = torch.full((rows * d_out + 4096,), 7.0, device="cuda")
+    z = nat.gemm_bf16x3_f32(x.cuda(), p.cuda())
+    assert z.shape == (rows, d_out) and z.dtype == torch.float32
+    ref = (x.cuda().double() @ p.cuda().double().T)
+    scale = float(ref.abs().max())
+    err = float((z.double() - ref).abs().max())
+    assert err < 4e-6 * scale, (err, scale)
+    assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
+
+
+@pytest.mark.parametrize("rows,d_in,d_out", [(25216, 1024, 384), (65792, 1280, 768), (3000, 1024, 384)])
+def test_token_gram_wide_at_training_sizes(nat, rows, d_in, d_out):
+    """student widths 384 / 768 (BASELINE c4 / c5): projection on the bf16x3 GEMM (first two cases) or the fp64-MFMA
+    batched GEMM (small M), Gram on the fp64 matrix cores"""
+    g = torch.Generator().manual_seed(rows + 1)
+    x = (torch.randn(rows, d_in, generator=g) + 2.0 * torch.randn(1, d_in, generator=g)).bfloat16().cuda()
+    p = torch.linalg.qr(torch.randn(d_in, d_out, generator=g))[0].T.contiguous().cuda()
+    gram, colsum = nat.token_gram(x, p, mirror=False)
+    z = x.double() @ p.double().T
+    ref, ref_sum = z.T @ z, z.sum(0)
+    low = torch.tril(torch.ones(d_out, d_out, dtype=torch.bool, device="cuda"))
+    assert torch.isfinite(gram[low]).all()
+    assert float((gram - ref)[low].abs().max()) < 3e-6 * float(ref.abs().max())
+    assert torch.allclose(colsum, ref_sum, rtol=0, atol=3e-6 * float(z.abs().sum(0).max()))
+
+
 def test_mp_rank_matches_oracle(nat):
     from oracle import basd_oracle as O
     g = torch.Generator().manual_seed(0)
@@ -817,6 +852,40 @@ def test_jacobi_converges_on_clustered_spectra(nat, batch):
     assert float(cos.max()) < 3e-6, float(cos.max())
     ref = torch.linalg.svdvals(a[:4])
     assert torch.allclose(sigma[:4].cpu().double(), ref, rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("batch", [16, 512])
+@pytest.mark.parametrize("case", ["rank 96 of 192", "graded to 1e-16", "graded to 1e-20, scaled 1e+6"])
+def test_jacobi_on_rank_deficient_cholesky_factors(nat, batch, case):
+    """the Jacobi input of the blocked eigensolver (functional._pair_rotation): F = L^T of the pivoted Cholesky factor
+    of a rank-deficient fp64 Gram matrix.  The cancelled directions leave debris columns (norm 1e-10 .. 1e-23 of the
+    largest) whose cosines with the real columns are noise: the rotation test must neither underflow on them
+    (tol^2 alpha beta ~ 1e-47) nor chase them sweep after sweep -- round 3 found a BASELINE c5 step in ~30 raising
+    NONCONVERGED from exactly such a matrix.  Both the odd-even (batch 16) and the block-ordering kernel (batch 512)."""
+    nat.check_status()
+    k = 192
+    g = torch.Generator().manual_seed(batch)
+    if case == "rank 96 of 192":
+        lam = torch.cat([torch.cos(torch.rand(96, dtype=torch.float64, generator=g) * 1.5707) ** 2, torch.zeros(96, dtype=torch.float64)])
+        scale = 1.0
+    elif case == "graded to 1e-16":
+        lam, scale = torch.logspace(0, -16, k, dtype=torch.float64), 1.0
+    else:
+        lam, scale = torch.logspace(0, -20, k, dtype=torch.float64), 1.0e6
+    q = torch.linalg.qr(torch.randn(batch, k, k, dtype=torch.float64, generator=g))[0]
+    gram = ((q * lam) @ q.transpose(1, 2) * scale).cuda()
+    _, lw, piv, rank = nat.pchol(gram, 1e-13)
+    wf = torch.zeros(batch, k, nat.jacobi_ld(k), dtype=torch.float32, device="cuda")
+    wf[:, :, :k] = lw.transpose(1, 2)
+    sigma, sweeps = nat.jacobi_svd(wf, k)
+    nat.check_status()                                        # raises if a matrix ran out of sweeps
+    assert int(sweeps.min()) > 0 and int(sweeps.max()) <= 34, (int(sweeps.min()), int(sweeps.max()))
+    # the singular values above the Cholesky cut are the square roots of the Gram eigenvalues, to fp32 RELATIVE accuracy
+    ref = (lam * scale).sqrt().sort(descending=True)[0]
+    r = int(rank.min())
+    keep = ref[:r] > 3e-5 * ref[0]                            # (the cut itself perturbs the values next to it)
+    got = sigma[:, :r].cpu().double()
+    assert torch.allclose(got[:, keep], ref[:r][keep].expand(batch, -1), rtol=3e-4, atol=0)
 
 
 @pytest.mark.parametrize("B,T,H", [(3, 197, 3), (2, 65, 3), (2, 224, 6), (5, 17, 2), (2, 96, 12)])

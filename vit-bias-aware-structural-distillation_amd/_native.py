@@ -23,7 +23,7 @@ EXPORTS = (
     "basd_mp_rank", "basd_flag_if_exceeds_f64", "basd_angle_weights", "basd_ce_uwso",
     "basd_procrustes_workspace_bytes", "basd_procrustes_fwd", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
-    "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
+    "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_gemm_bf16x3_f32", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
 )
 
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "basd_wgrad_bf16_ws": (_P, _P, _I64, _I, _I, _P, _P, _P, _I64, _P),
     "basd_gemm_bf16": (_P, _P, _P, _P, _I64, _I, _I, _I, _I, _P),
     "basd_gemm_bf16_gelu_fwd": (_P, _P, _P, _P, _P, _I64, _I, _I, _I, _P),
+    "basd_gemm_bf16x3_f32": (_P, _P, _P, _I64, _I, _I, _P),
     "basd_gemm_bf16_gelu_bwd": (_P, _P, _P, _P, _I64, _I, _I, _I, _P),
     "basd_layernorm_fwd_bf16": (_P, _P, _P, _I64, _I, _F, _P, _P, _P, _P),
     "basd_add_layernorm_fwd_bf16": (_P, _P, _P, _P, _I64, _I, _F, _P, _P, _P, _P, _P, _I, _P),
@@ -165,7 +166,9 @@ def status_word(device) -> torch.Tensor:
 def raise_for_status(value: int) -> None:
     if value:
         what = "; ".join(text for bit, text in _STATUS_TEXT.items() if value & bit)
-        raise BasdLinAlgError(f"BASD kernels reported status {value}: {what}")
+        if value >> 8:        # diagnostics of a non-converged Jacobi solve (csrc/jacobi.hip, report_status)
+            what += f" [kernel variant {(value >> 8) & 15}, matrix {(value >> 12) & 0xffff}]"
+        raise BasdLinAlgError(f"BASD kernels reported status {value & 255}: {what}")
 
 
 def check_status(device=None) -> None:
@@ -193,7 +196,7 @@ _SPLIT_CACHE: dict = {}
 def split_bf16x3(proj: torch.Tensor) -> torch.Tensor:
     """fp32 [d_out, d_in] -> bf16 [3, d_out, d_in] with proj == hi + mid + lo to 2^-24 (cached per buffer)."""
     key = (proj.data_ptr(), proj._version, tuple(proj.shape))
-    hit = _SPLIT_CACHE.get(key)
+    hit = _SPLIT_CACHE.get(key, (None, None))[0]
     if hit is None:
         p = proj.detach().float()
         hi = p.bfloat16()
@@ -203,8 +206,41 @@ def split_bf16x3(proj: torch.Tensor) -> torch.Tensor:
         hit = torch.stack([hi, mid, lo]).contiguous()
         if len(_SPLIT_CACHE) > 16:
             _SPLIT_CACHE.clear()
-        _SPLIT_CACHE[key] = hit
+        _SPLIT_CACHE[key] = (hit, proj)            # holds proj: its address cannot be handed to another tensor meanwhile
     return hit
+
+
+def split_bf16x3_rows(proj: torch.Tensor) -> torch.Tensor:
+    """fp32 [d_out, d_in] -> bf16 [ceil(d_out / 256) * 256, 3 * d_in]: row n = (hi | mid | lo) of proj[n] side by side,
+    zero rows behind d_out (operand layout of basd_gemm_bf16x3_f32; cached per buffer)."""
+    key = ("rows", proj.data_ptr(), proj._version, tuple(proj.shape))
+    hit = _SPLIT_CACHE.get(key, (None, None))[0]
+    if hit is None:
+        d_out, d_in = proj.shape
+        s3 = split_bf16x3(proj)                                                     # [3, d_out, d_in]
+        hit = torch.zeros((d_out + 255) // 256 * 256, 3 * d_in, dtype=torch.bfloat16, device=proj.device)
+        hit[:d_out] = s3.permute(1, 0, 2).reshape(d_out, 3 * d_in)
+        _SPLIT_CACHE[key] = (hit, proj)
+    return hit
+
+
+def gemm_bf16x3_f32_supported(m: int, n: int, k: int) -> bool:
+    return m > 7 * 256 and k % 64 == 0 and k >= 128 and n % 8 == 0
+
+
+def gemm_bf16x3_f32(x: torch.Tensor, proj: torch.Tensor) -> torch.Tensor:
+    """x [M, K] bf16, proj [N, K] fp32 -> x proj^T [M, N] fp32: ONE persistent bf16-MFMA GEMM of depth 3 K over the
+    (hi | mid | lo) bf16 splits of proj, fp32 accumulation across all three (x is exact in bf16, proj to 2^-24)."""
+    _need_cuda(x, proj)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and proj.dim() == 2 and x.shape[1] == proj.shape[1]
+    x = x.contiguous()
+    m, k = x.shape
+    n = proj.shape[0]
+    w3 = split_bf16x3_rows(proj.contiguous().float())
+    z = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    _check(lib().basd_gemm_bf16x3_f32(_ptr(x), _ptr(w3), _ptr(z), ctypes.c_int64(m), n, k, _stream()),
+           "basd_gemm_bf16x3_f32")
+    return z
 
 
 def _token_view(x: torch.Tensor):
@@ -237,12 +273,16 @@ def _split_rows(m: int) -> int:
 def _token_gram_wide(x: torch.Tensor, proj: torch.Tensor):
     """d_out > 256 (student widths 384 / 768, BASELINE c4 / c5): the fused one-pass kernel keeps a [128, d_out] z tile
     and d_out^2 / 256 fp64 accumulator tiles on chip, which stops at 256 columns.  Here z = X P^T is materialised in
-    fp32 (fp64-accumulated batched GEMM, own kernel) and z^T z runs on the fp64 matrix cores as a split-K batched GEMM (basd_bgemm_f64,
-    symmetric tiles only) followed by the slab sum."""
-    # z = X P^T on the own fp64-MFMA batched GEMM (fp32 out): a library GEMM here would be the only one of the teacher
-    # branch, i.e. the only reason not to run that branch on its own stream (trainer.py, _ensure_stream_policy)
-    x2 = x.reshape(-1, x.shape[-1]).float()
-    z = bgemm_f64(x2.unsqueeze(0), proj.unsqueeze(0), trans_b=True, out_dtype=torch.float32)[0]     # [M, d_out] fp32
+    fp32 and z^T z runs on the fp64 matrix cores as a split-K batched GEMM (basd_bgemm_f64, symmetric tiles only)
+    followed by the slab sum.  z = X P^T is an own kernel either way (a library GEMM here would be the only one of the
+    teacher branch, i.e. the only reason not to run that branch on its own stream: trainer.py, _ensure_stream_policy):
+    bf16 tokens at training sizes take the bf16x3 persistent GEMM (basd_gemm_bf16x3_f32: 24 x 0.1 ms at BASELINE c4;
+    the fp64-MFMA batched GEMM at batch 1 needed 2.6 ms per layer there), anything else the fp64-MFMA one."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype == torch.bfloat16 and gemm_bf16x3_f32_supported(x2.shape[0], proj.shape[0], x2.shape[1]):
+        z = gemm_bf16x3_f32(x2, proj)
+    else:
+        z = bgemm_f64(x2.float().unsqueeze(0), proj.unsqueeze(0), trans_b=True, out_dtype=torch.float32)[0]
     m, d = z.shape
     s = _split_rows(m)
     zs = z.view(s, m // s, d)
@@ -307,7 +347,7 @@ def pchol(a: torch.Tensor, tol: float = 1e-13, dmax_ref: torch.Tensor | None = N
 
 
 def jacobi_svd(w: torch.Tensor, m_rows: int, norm_rows: int | None = None, *, tol: float | None = None,
-               max_sweeps: int = 40, sort: bool = True, active: torch.Tensor | None = None,
+               max_sweeps: int = 60, sort: bool = True, active: torch.Tensor | None = None,
                active_rows: bool = False, flag_status: bool = True):
     """In-place one-sided Jacobi on w [batch, n_cols, ld] (column-major matrices).
 

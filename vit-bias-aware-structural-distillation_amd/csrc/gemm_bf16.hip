@@ -383,12 +383,45 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const unsigned shor
 // the columns h * 32 + q'' * 8 + [0, 8) for h = 0, 1, i.e. two 16-byte pieces, and one dwordx4 store instruction of the
 // wave writes 16 rows x 64 contiguous bytes.  16 swaps per row block; bias / GELU / the saved pre-activation are applied
 // in that final layout (16-byte loads).  Leaves the LDS ring alone, so the operands of the NEXT tile keep streaming in.
+// EPI 5: fp32 output of pitch N, columns >= N are not stored (the weight matrix is padded to the tile width, the output
+// is not): two 16-byte stores per 8 columns.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_direct(gf32x4 (&acc)[4][8], const unsigned short* bias,
                                                      unsigned short* aux, unsigned short* Y, int M, int N, int row0,
                                                      int col0, int lane) {
   typedef unsigned int eu32x2 __attribute__((ext_vector_type(2)));
   const int q = lane >> 4, r16 = lane & 15;
+  if constexpr (EPI == 5) {
+    float* Y32 = reinterpret_cast<float*>(Y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v[4][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          eu32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[2 * p][j][r]),
+                                                       __float_as_uint(acc[2 * p + 1][j][r]), false, false);
+          eu32x2 s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+          v[2 * p][r] = __uint_as_float(s2[0]);
+          v[2 * p + 1][r] = __uint_as_float(s2[1]);
+        }
+      const int row = row0 + j * 16 + r16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = col0 + h * 32 + q * 8;
+        if (row < M && col < N) {
+          float* dst = Y32 + (size_t)row * N + col;
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            __builtin_nontemporal_store((gu32x4){__float_as_uint(v[2 * h + k][0]), __float_as_uint(v[2 * h + k][1]),
+                                                 __float_as_uint(v[2 * h + k][2]), __float_as_uint(v[2 * h + k][3])},
+                                        reinterpret_cast<gu32x4*>(dst + 4 * k));
+        }
+      }
+    }
+    return;
+  }
   float bv[2][8];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -493,10 +526,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ bias,
                                                               unsigned short* aux, unsigned short* __restrict__ Y,
                                                               int M, int N, int K, int tiles_n, int mblocks, int ngroup,
-                                                              int chunk_tiles) {
+                                                              int chunk_tiles, int ka) {
+  // EPI 5 (bf16x3 product, fp32 out): the activation panel has row pitch ka and is walked K / ka times (once per
+  // split of the weights, whose rows hold the splits side by side: pitch K = 3 ka); N = columns stored = output pitch.
   extern __shared__ __align__(16) unsigned char g_lds[];
   constexpr int NT = 4, UNIT = 32768, NSLOT = 5;
   constexpr int NST = (EPI == 3) ? 32 : 16;                 // global stores of a wave per epilogue
+  const int KA = EPI == 5 ? ka : K;                         // row pitch of the activation panel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -539,7 +575,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
       const int s = wave + 8 * j;
       int m = m0_ + (s >> 1) * 16 + dma_row;
       m = m < M ? m : M - 1;
-      off_a[j] = (unsigned int)(((m - m0_) * K + (s & 1) * 32 + dma_c16 * 8) * 2);
+      off_a[j] = (unsigned int)(((m - m0_) * KA + (s & 1) * 32 + dma_c16 * 8) * 2);
     }
   };
   // SGPR base + 32-bit lane offset (the saddr form: hipcc widens the offsets to 64-bit VGPR pairs and adds them on the
@@ -607,7 +643,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
   // ---- first segment
   int m0, n0;
   tile_at(o, m0, n0);
-  const unsigned char* a_cur = reinterpret_cast<const unsigned char*>(X) + (size_t)m0 * K * 2;
+  const unsigned char* a_cur = reinterpret_cast<const unsigned char*>(X) + (size_t)m0 * KA * 2;
   const unsigned char* b_cur = reinterpret_cast<const unsigned char*>(W) + (size_t)n0 * K * 2;
   set_off_a(m0);
   // ---- prologue: the units A, B of the first two steps into slots 0..3; the first step's fragments into registers
@@ -632,12 +668,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
     // into ring slots nobody multiplies (keeps every step identical; drained before the kernel ends)
     int m0n = m0, n0n = n0;
     if (has_next) tile_at(o + 1, m0n, n0n);
-    const unsigned char* a_nxt = reinterpret_cast<const unsigned char*>(X) + (size_t)m0n * K * 2;
+    const unsigned char* a_nxt = reinterpret_cast<const unsigned char*>(X) + (size_t)m0n * KA * 2;
     const unsigned char* b_nxt = reinterpret_cast<const unsigned char*>(W) + (size_t)n0n * K * 2;
 #pragma nounroll
     for (int t = 0; t < nk; ++t) {
       if (t == nk - 2) set_off_a(m0n);                      // every A unit of this tile has been issued
-      const unsigned char* a_src = t + 2 < nk ? a_cur + (t + 2) * (GBK * 2) : a_nxt + (t + 2 - nk) * (GBK * 2);
+      int ta = t + 2;                                       // K step of the activation panel (EPI 5: modulo its depth)
+      if (EPI == 5 && ta < nk) {
+        const int nka = KA / GBK;
+        ta -= ta >= nka ? nka : 0;
+        ta -= ta >= nka ? nka : 0;
+      }
+      const unsigned char* a_src = t + 2 < nk ? a_cur + ta * (GBK * 2) : a_nxt + (t + 2 - nk) * (GBK * 2);
       const unsigned char* b_src = t + 2 < nk ? b_cur + (t + 2) * (GBK * 2) : b_nxt + (t + 2 - nk) * (GBK * 2);
       const int s_b = wrap(slot + 1), s_a1 = wrap(slot + 2), s_b1 = wrap(slot + 3), s_a2 = wrap(slot + 4);
       // ---- k-block 0
@@ -664,8 +706,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
     }
     const bool full_rows = m0 + GBM <= M;                   // every store of the epilogue is issued by every wave
     gemm_epilogue_direct<EPI>(acc, bias, aux, Y, M, N, m0 + wm * 128, n0 + wn * 64, lane);
-    st_pending = full_rows ? NST : 0;
-    if (!full_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ragged rows: not every wave issues every store
+    st_pending = (full_rows && EPI != 5) ? NST : 0;
+    if (!full_rows || EPI == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ragged rows (EPI 5: columns): not every wave issues every store
     if (!has_next) break;
     ++o;
     m0 = m0n;
@@ -711,8 +753,8 @@ static int pring_cus_per_xcd(int M, int N) {
 
 template <int EPI>
 static void launch_gemm_pring(const void* x, const void* w, const void* bias, void* aux, void* y, int M, int N, int K,
-                              int tile_run, hipStream_t st) {
-  const int tiles_n = N / 256, mblocks = (M + GBM - 1) / GBM;
+                              int tile_run, hipStream_t st, int ka = 0) {
+  const int tiles_n = (N + 255) / 256, mblocks = (M + GBM - 1) / GBM;
   const int ngroup = gemm_column_group(tiles_n, 256, K);
   const int chunk_tiles = tile_run > 0 ? tile_run : 1 << 20;
   const int max_block = ((mblocks + 7) / 8 * tiles_n + 31) / 32;
@@ -721,7 +763,7 @@ static void launch_gemm_pring(const void* x, const void* w, const void* bias, vo
   allow_full_lds((const void*)gemm_bf16_pring_kernel<EPI>);
   hipLaunchKernelGGL((gemm_bf16_pring_kernel<EPI>), dim3(grid), dim3(512), 5 * 32768, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
-                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup, chunk_tiles);
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup, chunk_tiles, ka);
 }
 
 template <int BN, int EPI>
@@ -799,6 +841,18 @@ extern "C" int basd_gemm_bf16(const void* x, const void* w, const void* bias, vo
   if (epilogue < 0 || epilogue > 2) return fail(BASD_ERR_SHAPE, "gemm_bf16: epilogue %d not in {0, 1, 2}", epilogue);
   if (epilogue == 1 && bias == nullptr) epilogue = 0;
   return gemm_dispatch(x, w, bias, nullptr, y, M, N, K, epilogue, tile_run, stream, "gemm_bf16");
+}
+
+extern "C" int basd_gemm_bf16x3_f32(const void* x, const void* w3, float* y, int64_t M, int N, int K, void* stream) {
+  using namespace basd;
+  if (M <= 0) return BASD_OK;
+  if (M > 0x7fffff00LL) return fail(BASD_ERR_SHAPE, "gemm_bf16x3_f32: M = %lld too large", (long long)M);
+  if (K % GBK || K < GBK || N < 1 || N % 8)
+    return fail(BASD_ERR_SHAPE, "gemm_bf16x3_f32: need K %% 64 == 0 and N %% 8 == 0 (got N=%d K=%d)", N, K);
+  if ((M + GBM - 1) / GBM < 8) return fail(BASD_ERR_SHAPE, "gemm_bf16x3_f32: needs M > 1792 rows (got %lld)", (long long)M);
+  if (K < 2 * GBK) return fail(BASD_ERR_SHAPE, "gemm_bf16x3_f32: K >= 128 required (got %d)", K);
+  launch_gemm_pring<5>(x, w3, nullptr, nullptr, y, (int)M, N, 3 * K, 0, (hipStream_t)stream, K);
+  return check_launch("gemm_bf16x3_f32");
 }
 
 extern "C" int basd_gemm_bf16_gelu_fwd(const void* x, const void* w, const void* bias, void* pre, void* y, int64_t M,

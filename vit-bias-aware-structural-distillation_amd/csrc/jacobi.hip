@@ -15,18 +15,31 @@
 
 namespace basd {
 
+// a pair whose squared-norm product is below this (denormal or flushed: one of the columns is debris of norm < 1e-19
+// next to a unit column) is left alone: its "cosine" is the quotient of two underflowed numbers
+#define BASD_JACOBI_TINY 1.0e-37f
+// Debris: a column whose squared norm has fallen below DEBRIS x the largest of its matrix (norm ratio 1e-10) is the
+// rounding residue of a cancelled direction (rank-deficient input: the pivoted Cholesky factors these kernels are fed
+// keep every real column above 3e-7 of the largest).  Its direction is noise, so its cosines with the real columns are
+// O(1) again after every rotation that shrinks it: left in the game it asks for LARGE rotations sweep after sweep until
+// it underflows (measured: 192 columns of rank 96 used all 40 sweeps).  Such columns are left alone.
+#define BASD_JACOBI_DEBRIS 1.0e-20f
+
 // Health word (optional, one int32 per launch set, OR-ed with atomics): BASD_STATUS_NONCONVERGED when a matrix used
 // all max_sweeps sweeps and was still rotating, BASD_STATUS_NONFINITE when a singular value is NaN / Inf (a NaN input
 // makes every rotation test false, so such a matrix "converges" at once and would otherwise pass silently).
+// Bits 8 .. 27 of the word are diagnostics of a non-converged solve (informational; OR-ed like the rest, so exact
+// for the usual single offender): bits 8-11 the kernel variant (1 LDS-resident, 2 / 3 odd-even with a double / single
+// mailbox, 4 two matrices per workgroup, 5 block ordering), bits 12-27 the matrix index (saturating at 65535).
 __device__ __forceinline__ void report_status(int32_t* status, bool converged, const float* s_sig, int n, int tid,
-                                              int nthreads) {
+                                              int nthreads, int kind, int mat) {
   if (!status) return;
   int st = 0;
   for (int c = tid; c < n; c += nthreads) {
     const float v = s_sig[c];
     if (!(v == v) || v > 3.0e38f) st |= BASD_STATUS_NONFINITE;
   }
-  if (tid == 0 && !converged) st |= BASD_STATUS_NONCONVERGED;
+  if (tid == 0 && !converged) st |= BASD_STATUS_NONCONVERGED | ((kind & 15) << 8) | ((mat > 65535 ? 65535 : mat) << 12);
   if (st) atomicOr(status, st);
 }
 
@@ -91,7 +104,10 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
         beta = group8_sum(beta);
         gamma = group8_sum(gamma);
         // |gamma| > tol sqrt(alpha beta), without the sqrt
-        if (gamma * gamma > tol * tol * alpha * beta && gamma != 0.f) {
+        // (the cosine is scaled UP by 1 / tol before squaring: tol^2 alpha beta underflows for graded factors -- a
+        // column of norm 1e-17 against one of norm 1 -- and the test then degenerates to gamma^2 > 0)
+        const float gsc = gamma * (1.0f / tol);
+        if (gsc * gsc > alpha * beta && alpha * beta > BASD_JACOBI_TINY && gamma != 0.f) {
           rotated = true;
           // The rotation ANGLE may be approximate (hardware rcp / sqrt, 1 ulp): any t gives an exact
           // plane rotation as long as (c, s) are consistent.  Only c = (1 + t^2)^(-1/2) is refined
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
     *reinterpret_cast<float4*>(src + (size_t)dst * ld + r) = reinterpret_cast<const float4*>(W)[i];
   }
   if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = converged ? used_sweeps : -used_sweeps;
-  report_status(status, converged, s_sig, n, tid, nthreads);
+  report_status(status, converged, s_sig, n, tid, nthreads, 1, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,9 +287,15 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
       Y[mi][ch] = (in && idY[mi] < na) ? *reinterpret_cast<const v4f*>(src[mi] + (size_t)idY[mi] * ld + r) : (v4f){0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (tid < 4) s_flag[tid] = 0;
+  if (tid < 8) s_flag[tid] = 0;                    // [4 + 2 mi + parity]: largest squared column norm of the sweep
   __syncthreads();
 
+  // rotation test |gamma| > tol sqrt(alpha beta) as (gamma / tol)^2 > alpha beta: with the tolerance on the right-hand
+  // side (tol^2 alpha beta ~ 7e-13 alpha beta) the product underflows for the graded factors of rank-deficient Gram
+  // matrices (a column of norm 1e-17 next to one of norm 1: the debris of cancelled directions) and the test
+  // degenerates to gamma^2 > 0 -- such pairs then rotate, and count as LARGE rotations, on noise, sweep after sweep
+  // (seen at BASELINE c5: a principal-angle problem of the 768-wide selector used all 40 sweeps once in ~30 steps)
+  const float inv_tol = 1.0f / tol;
   int used_sweeps = 0;
   bool converged = false;
   int step = 0;                                    // global step counter: even = (2k, 2k+1) view
@@ -293,7 +315,12 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
       }
       nX[mi] = group8_sum(ax);
       nY[mi] = group8_sum(ay);
+      if (live[mi] && sub == 0) atomicMax(&s_flag[4 + 2 * mi + (sweep & 1)], __float_as_int(fmaxf(nX[mi], nY[mi])));
     }
+    __syncthreads();
+    float debris[NMAT];
+#pragma unroll
+    for (int mi = 0; mi < NMAT; ++mi) debris[mi] = __int_as_float(s_flag[4 + 2 * mi + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
 #pragma unroll 1
     for (int t = 0; t < n_loop; ++t, ++step) {
       const bool even_view = (step & 1) == 0;
@@ -311,9 +338,10 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
             gamma = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, gamma))));
           }
           gamma = group8_sum(gamma);
-          if (gamma * gamma > tol * tol * alpha * beta && gamma != 0.f) {
+          const float gsc = gamma * inv_tol, gq = gamma * (1.0f / BASD_JACOBI_QUAD);
+          if (gsc * gsc > alpha * beta && alpha * beta > BASD_JACOBI_TINY && fminf(alpha, beta) >= debris[mi] && gamma != 0.f) {
             rotated = true;
-            const bool big_cos = gamma * gamma > BASD_JACOBI_QUAD * BASD_JACOBI_QUAD * alpha * beta;
+            const bool big_cos = gq * gq > alpha * beta;
             const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
             const float tt = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.f)));
             bigrot = bigrot || big_cos || fabsf(tt) > BASD_JACOBI_QUAD_TAN;
@@ -387,7 +415,10 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
     if (bigrot) s_flag[2 + (sweep & 1)] = 1;
     __syncthreads();
     const int any = s_flag[sweep & 1], anybig = s_flag[2 + (sweep & 1)];
-    if (tid == 0) { s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0; }
+    if (tid == 0) {
+      s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0;
+      s_flag[4 + ((sweep + 1) & 1)] = 0; s_flag[6 + ((sweep + 1) & 1)] = 0;
+    }
     __syncthreads();
     if (!any || !anybig) { converged = true; break; }
   }
@@ -462,7 +493,7 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
     }
     if (sweeps_out && tid == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
     __syncthreads();
-    report_status(status, converged, s_sig, n_tot, tid, blockDim.x);
+    report_status(status, converged, s_sig, n_tot, tid, blockDim.x, NMAT == 2 ? 4 : (NBUF == 2 ? 2 : 3), mat);
   }
 }
 
@@ -513,10 +544,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                : (v4f){0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (tid < 4) s_flag[tid] = 0;
+  if (tid < 8) s_flag[tid] = 0;                    // [4 + parity]: largest squared column norm of the sweep
   __syncthreads();
 
-  const float tol2 = tol * tol;
+  const float inv_tol = 1.0f / tol;
+  float debris = 0.f;                              // squared norm below which a column is rounding residue (per sweep)
   bool rotated = false, bigrot = false;
   // one plane rotation of the column pair (A, B); the caller issues two independent ones back to back
   auto rot1 = [&](v4f (&A)[MAXCH], v4f (&B)[MAXCH], float& na, float& nb_, bool ok) {
@@ -529,9 +561,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     const float g = group8_sum(ga + gb);
     const float al = na, be = nb_;
-    if (ok && g * g > tol2 * al * be && g != 0.f) {
+    const float gsc = g * inv_tol, gq = g * (1.0f / BASD_JACOBI_QUAD);     // scaled up before squaring: see jacobi_oe_kernel
+    if (ok && gsc * gsc > al * be && al * be > BASD_JACOBI_TINY && fminf(al, be) >= debris && g != 0.f) {
       rotated = true;
-      const bool big_cos = g * g > BASD_JACOBI_QUAD * BASD_JACOBI_QUAD * al * be;
+      const bool big_cos = gq * gq > al * be;
       const float z = (be - al) * __builtin_amdgcn_rcpf(2.f * g);
       const float t = copysignf(1.f, z) * __builtin_amdgcn_rcpf(fabsf(z) + __builtin_amdgcn_sqrtf(fmaf(z, z, 1.f)));
       bigrot = bigrot || big_cos || fabsf(t) > BASD_JACOBI_QUAD_TAN;
@@ -571,6 +604,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
       nr[c] = group8_sum(a);
     }
+    if (live && sub == 0)
+      atomicMax(&s_flag[4 + (sweep & 1)], __float_as_int(fmaxf(fmaxf(nr[0], nr[1]), fmaxf(nr[2], nr[3]))));
+    __syncthreads();
+    debris = __int_as_float(s_flag[4 + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
     rot2(C[0], C[1], nr[0], nr[1], C[2], C[3], nr[2], nr[3], live);       // the pair inside each block
 #pragma unroll 1
     for (int t = 0; t < nbe; ++t, ++step) {
@@ -645,7 +682,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (bigrot) s_flag[2 + (sweep & 1)] = 1;
     __syncthreads();
     const int any = s_flag[sweep & 1], anybig = s_flag[2 + (sweep & 1)];
-    if (tid == 0) { s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0; }
+    if (tid == 0) { s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0; s_flag[4 + ((sweep + 1) & 1)] = 0; }
     __syncthreads();
     if (!any || !anybig) { converged = true; break; }
   }
@@ -702,7 +739,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
   if (sweeps_out && tid == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
-  report_status(status, converged, s_sig, n_tot, tid, blockDim.x);
+  report_status(status, converged, s_sig, n_tot, tid, blockDim.x, 5, mat);
 }
 
 }  // namespace basd

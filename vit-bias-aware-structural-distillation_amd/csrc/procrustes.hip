@@ -110,7 +110,7 @@ static int polar_core(const double* gram, int batch, int r, double tol, Procrust
   const int ld = jacobi_ld_of(r);
   const int F32 = BASD_DTYPE_F32, F64 = BASD_DTYPE_F64;
   BASD_TRY(basd_pchol_f64(gram, batch, r, tol, nullptr, p.w0, ld, lwork, p.piv, p.rank, st));
-  BASD_TRY(basd_jacobi_svd(p.w0, batch, r, r, ld, r, sqrtf((float)r) * 5.96e-8f, 40, 1, p.sigma, nullptr, nullptr, 0,
+  BASD_TRY(basd_jacobi_svd(p.w0, batch, r, r, ld, r, sqrtf((float)r) * 5.96e-8f, 60, 1, p.sigma, nullptr, nullptr, 0,
                            status, st));
   BASD_TRY(basd_trinv_f64(lwork, p.piv, p.rank, batch, r, l_inv, st));
   // J1 = L^-1 (U Sigma): l_inv [k, r] x (w0 [i, r])^T -> [k, i]; w0 is read in place through its leading dimension
