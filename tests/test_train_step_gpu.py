@@ -299,13 +299,13 @@ def test_vit_huge_teacher_stays_on_the_hip_path_in_strict_mode():
     assert torch.allclose(imps[0], want, rtol=5e-2, atol=2e-5)
 
 
-def _make_preset(student, teacher, batch, img=224, patch=16):
+def _make_preset(student, teacher, batch, img=224, patch=16, extra=()):
     from basd_amd.config import load_config
     from basd_amd.train import SyntheticLoader, build
     torch.manual_seed(0)
     cfg = load_config(CFG, None, [f"data.batch_size={batch}", "data.dataset=synthetic", f"model.student_preset={student}",
                                   f"basd.teacher_model_name={teacher}", f"model.vit.img_size={img}",
-                                  f"model.vit.patch_size={patch}", "model.drop_path_rate=0.0"])
+                                  f"model.vit.patch_size={patch}", "model.drop_path_rate=0.0"] + list(extra))
     trainer, _ = build(cfg, device="cuda")
     trainer.use_mixup = False
     trainer.optimizer.train()
@@ -314,14 +314,17 @@ def _make_preset(student, teacher, batch, img=224, patch=16):
     return trainer, b
 
 
-@pytest.mark.parametrize("student,teacher,batch", [("deit_tiny_patch16_224", "vit_base_patch16_224", 8),
-                                                   ("vit_base_patch16_224", "vit_huge_patch14_224", 2)])
-def test_a_train_step_has_no_library_fallback_in_strict_mode(student, teacher, batch):
-    """BASELINE configs[1] and configs[4] model pairs at a small batch, BASD_STRICT semantics: no ViT block, patch
-    embedding or attention of either model leaves the hand-written kernels during a whole step (the 1000-class head is
-    the one declared library call)"""
+@pytest.mark.parametrize("student,teacher,batch,img,patch", [
+    ("deit_tiny_patch16_224", "vit_base_patch16_224", 8, 224, 16),
+    ("vit_base_patch16_224", "vit_huge_patch14_224", 2, 224, 16),
+    ("deit_tiny_patch16_224", "vit_small_patch16_224", 16, 32, 4)])
+def test_a_train_step_has_no_library_fallback_in_strict_mode(student, teacher, batch, img, patch):
+    """BASELINE configs[1], configs[4] and configs[0] (32 x 32 images, 48-value patches) model pairs at a small batch,
+    BASD_STRICT semantics: no ViT block, patch embedding or attention of either model leaves the hand-written kernels
+    during a whole step (the 1000-class head is the one declared library call)"""
     import basd_amd.losses._ops as O
-    trainer, b = _make_preset(student, teacher, batch)
+    trainer, b = _make_preset(student, teacher, batch, img, patch,
+                              extra=[f"basd.teacher_patch_size={patch}"] if img == 32 else ())
     O.FALLBACKS.clear()
     O.set_strict(True)
     try:
@@ -331,6 +334,30 @@ def test_a_train_step_has_no_library_fallback_in_strict_mode(student, teacher, b
         O.set_strict(False)
     assert float(loss) == float(loss)
     assert not O.FALLBACKS, dict(O.FALLBACKS)
+
+
+def test_short_patch_embedding_trains_on_the_own_kernels():
+    """3 x 4 x 4 = 48-value patches (BASELINE configs[0]): K zero-padded to 64 in front of basd_gemm_bf16 /
+    basd_wgrad_bf16; output and weight / bias gradients against the fp32 convolution"""
+    import basd_amd.losses._ops as O
+    from basd_amd.models.vit import PatchEmbed
+    torch.manual_seed(3)
+    pe = PatchEmbed(32, 4, 3, 192).cuda()
+    x = torch.randn(64, 3, 32, 32, device="cuda")
+    g = torch.randn(64, 64, 192, device="cuda")
+    O.FALLBACKS.clear()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = pe(x)
+    assert not O.FALLBACKS, dict(O.FALLBACKS)
+    y.backward(g.to(y.dtype))
+    gw, gb = pe.proj.weight.grad.clone(), pe.proj.bias.grad.clone()
+    pe.zero_grad()
+    ref = torch.nn.functional.conv2d(x, pe.proj.weight, pe.proj.bias, stride=4).flatten(2).transpose(1, 2)
+    ref.backward(g)
+    assert y.shape == ref.shape and float((y.detach().float() - ref.detach()).abs().max()) < 3e-2 * float(ref.detach().abs().max())
+    for got, want in ((gw, pe.proj.weight.grad), (gb, pe.proj.bias.grad)):
+        assert got.shape == want.shape
+        assert float((got - want).norm() / want.norm()) < 1e-2
 
 
 def test_two_streams_at_vit_base_vit_huge_widths():

@@ -403,6 +403,14 @@ class PatchEmbed(nn.Module):
                 cache = (self.proj.weight._version, w_pad)
                 self._w_pad = cache
             return ops.gemm_bf16(patches, cache[1], self.proj.bias)
+        if (ops.handles(x) and trained and self._bf16_compute(x) and self.proj.bias is not None
+                and ops.gemm_supported(d, k_pad) and ops.wgrad_supported(d, k_pad)):
+            # trained layer with a short patch (BASELINE c1: 3 x 4 x 4 = 48 values): the same zero padding of K, the
+            # weight padded per step inside the autograd function, its gradient cut back to [D, K]
+            patches = torch.zeros(b, (h // p) * (w // p), k_pad, dtype=torch.bfloat16, device=x.device)
+            patches[..., :k].view(b, h // p, w // p, c, p, p).copy_(unfolded)
+            with torch.autocast(device_type=x.device.type, enabled=False):
+                return _PaddedPatchFn.apply(patches, self.proj.weight.view(d, k), self.proj.bias)
         if ops.handles(x):
             library_fallback("patch embedding", f"K={k} D={d} dtype={x.dtype}")
         return F.linear(unfolded.reshape(b, -1, k), self.proj.weight.reshape(d, -1), self.proj.bias)
@@ -412,6 +420,28 @@ class PatchEmbed(nn.Module):
             return True                                      # frozen bf16 teacher
         dev = x.device.type
         return torch.is_autocast_enabled(dev) and torch.get_autocast_dtype(dev) == torch.bfloat16
+
+
+class _PaddedPatchFn(torch.autograd.Function):
+    """patches [B, N, K_pad] bf16 (zero beyond K) x weight [D, K] fp32 master + bias: forward on basd_gemm_bf16 with the
+    weight zero-padded to K_pad, weight / bias gradient on basd_wgrad_bf16 (the K_pad - K extra columns are dropped).
+    The images need no gradient."""
+
+    @staticmethod
+    def forward(ctx, patches, weight, bias):
+        d, k = weight.shape
+        w16 = torch.zeros(d, patches.shape[-1], dtype=torch.bfloat16, device=patches.device)
+        w16[:, :k].copy_(weight)
+        ctx.save_for_backward(patches)
+        ctx.k = k
+        return get_ops().gemm_bf16(patches, w16, bias.to(torch.bfloat16))
+
+    @staticmethod
+    def backward(ctx, g):
+        (patches,) = ctx.saved_tensors
+        g16 = g.to(torch.bfloat16).contiguous()
+        gw, gb = get_ops().wgrad_bf16(g16.reshape(-1, g16.shape[-1]), patches.reshape(-1, patches.shape[-1]), need_bias=True)
+        return None, gw[:, :ctx.k].contiguous(), gb
 
 
 def _matrix_view(weight: torch.Tensor) -> torch.Tensor:
