@@ -15,14 +15,16 @@
 
 namespace basd {
 
-// a pair whose squared-norm product is below this (denormal or flushed: one of the columns is debris of norm < 1e-19
-// next to a unit column) is left alone: its "cosine" is the quotient of two underflowed numbers
+// floor of the squared-norm product in the rotation test (gamma / tol)^2 > max(alpha beta, TINY): below it the product
+// is denormal or flushed (both columns under 1e-19: under-scaled input) and the "cosine" would be the quotient of two
+// underflowed numbers
 #define BASD_JACOBI_TINY 1.0e-37f
 // Debris: a column whose squared norm has fallen below DEBRIS x the largest of its matrix (norm ratio 1e-10) is the
 // rounding residue of a cancelled direction (rank-deficient input: the pivoted Cholesky factors these kernels are fed
 // keep every real column above 3e-7 of the largest).  Its direction is noise, so its cosines with the real columns are
 // O(1) again after every rotation that shrinks it: left in the game it asks for LARGE rotations sweep after sweep until
-// it underflows (measured: 192 columns of rank 96 used all 40 sweeps).  Such columns are left alone.
+// it underflows (measured: 192 columns of rank 96 used all 40 sweeps).  Such columns are set to zero at the start of a
+// sweep (the exact norms and the largest of them are at hand there): sigma = 0, never rotated again.
 #define BASD_JACOBI_DEBRIS 1.0e-20f
 
 // Health word (optional, one int32 per launch set, OR-ed with atomics): BASD_STATUS_NONCONVERGED when a matrix used
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(
         // (the cosine is scaled UP by 1 / tol before squaring: tol^2 alpha beta underflows for graded factors -- a
         // column of norm 1e-17 against one of norm 1 -- and the test then degenerates to gamma^2 > 0)
         const float gsc = gamma * (1.0f / tol);
-        if (gsc * gsc > alpha * beta && alpha * beta > BASD_JACOBI_TINY && gamma != 0.f) {
+        if (gsc * gsc > fmaxf(alpha * beta, BASD_JACOBI_TINY)) {
           rotated = true;
           // The rotation ANGLE may be approximate (hardware rcp / sqrt, 1 ulp): any t gives an exact
           // plane rotation as long as (c, s) are consistent.  Only c = (1 + t^2)^(-1/2) is refined
@@ -318,9 +320,18 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
       if (live[mi] && sub == 0) atomicMax(&s_flag[4 + 2 * mi + (sweep & 1)], __float_as_int(fmaxf(nX[mi], nY[mi])));
     }
     __syncthreads();
-    float debris[NMAT];
 #pragma unroll
-    for (int mi = 0; mi < NMAT; ++mi) debris[mi] = __int_as_float(s_flag[4 + 2 * mi + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
+    for (int mi = 0; mi < NMAT; ++mi) {            // debris columns become exact zero columns (gamma = 0: never rotated)
+      const float debris = __int_as_float(s_flag[4 + 2 * mi + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
+      const bool zx = nX[mi] < debris, zy = nY[mi] < debris;
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) {
+        if (zx) X[mi][ch] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (zy) Y[mi][ch] = (v4f){0.f, 0.f, 0.f, 0.f};
+      }
+      if (zx) nX[mi] = 0.f;
+      if (zy) nY[mi] = 0.f;
+    }
 #pragma unroll 1
     for (int t = 0; t < n_loop; ++t, ++step) {
       const bool even_view = (step & 1) == 0;
@@ -338,9 +349,10 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
             gamma = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, gamma))));
           }
           gamma = group8_sum(gamma);
-          const float gsc = gamma * inv_tol, gq = gamma * (1.0f / BASD_JACOBI_QUAD);
-          if (gsc * gsc > alpha * beta && alpha * beta > BASD_JACOBI_TINY && fminf(alpha, beta) >= debris[mi] && gamma != 0.f) {
+          const float gsc = gamma * inv_tol;
+          if (gsc * gsc > fmaxf(alpha * beta, BASD_JACOBI_TINY)) {
             rotated = true;
+            const float gq = gamma * (1.0f / BASD_JACOBI_QUAD);
             const bool big_cos = gq * gq > alpha * beta;
             const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
             const float tt = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.f)));
@@ -548,7 +560,6 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __syncthreads();
 
   const float inv_tol = 1.0f / tol;
-  float debris = 0.f;                              // squared norm below which a column is rounding residue (per sweep)
   bool rotated = false, bigrot = false;
   // one plane rotation of the column pair (A, B); the caller issues two independent ones back to back
   auto rot1 = [&](v4f (&A)[MAXCH], v4f (&B)[MAXCH], float& na, float& nb_, bool ok) {
@@ -561,9 +572,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     const float g = group8_sum(ga + gb);
     const float al = na, be = nb_;
-    const float gsc = g * inv_tol, gq = g * (1.0f / BASD_JACOBI_QUAD);     // scaled up before squaring: see jacobi_oe_kernel
-    if (ok && gsc * gsc > al * be && al * be > BASD_JACOBI_TINY && fminf(al, be) >= debris && g != 0.f) {
+    // |g| > tol sqrt(al be) as (g / tol)^2 > al be (see jacobi_oe_kernel); a product below TINY (under-scaled input:
+    // both columns below 1e-19) is compared against TINY instead -- a coarser threshold there, never "any g != 0"
+    const float gsc = g * inv_tol;
+    if (ok && gsc * gsc > fmaxf(al * be, BASD_JACOBI_TINY)) {
       rotated = true;
+      const float gq = g * (1.0f / BASD_JACOBI_QUAD);
       const bool big_cos = gq * gq > al * be;
       const float z = (be - al) * __builtin_amdgcn_rcpf(2.f * g);
       const float t = copysignf(1.f, z) * __builtin_amdgcn_rcpf(fabsf(z) + __builtin_amdgcn_sqrtf(fmaf(z, z, 1.f)));
@@ -607,7 +621,17 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (live && sub == 0)
       atomicMax(&s_flag[4 + (sweep & 1)], __float_as_int(fmaxf(fmaxf(nr[0], nr[1]), fmaxf(nr[2], nr[3]))));
     __syncthreads();
-    debris = __int_as_float(s_flag[4 + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
+    {
+      const float debris = __int_as_float(s_flag[4 + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                // debris columns become exact zero columns (never rotated again)
+        const bool z = nr[c] < debris;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch)
+          if (z) C[c][ch] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (z) nr[c] = 0.f;
+      }
+    }
     rot2(C[0], C[1], nr[0], nr[1], C[2], C[3], nr[2], nr[3], live);       // the pair inside each block
 #pragma unroll 1
     for (int t = 0; t < nbe; ++t, ++step) {
