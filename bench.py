@@ -289,7 +289,7 @@ def main():
             traffic = None
             if big == 1024 and big_n == 192:      # the committed PMC passes were taken at this launch shape
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
+                    with open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")) as f:
                         for key, v in json.load(f)["kernels"].items():
                             if key.startswith("basd::jacobi_blk_kernel<6>"):
                                 traffic = v["hbm_bytes_per_launch"]
@@ -313,7 +313,7 @@ def main():
                                     "basd_procrustes_fwd: the probe steps launch that entry's kernels one by one; "
                                     "rocprofv3 of the same command sees the graph-launched kernels: profiles/)"),
                     "mean_sweeps": sweep_sum / max(mats, 1),
-                    "traffic_source": "constant from the committed PMC passes (profiles/r02_pmc_hbm_traffic.json), not "
+                    "traffic_source": "constant from the committed PMC passes (profiles/r03_pmc_hbm_traffic.json), not "
                                       "measured in this run" if traffic is not None else None,
                     "note": "VALU kernel priced against the fp32 vector = matrix peak; algorithmic (textbook) "
                             "flops = sweeps actually run (returned per matrix by the kernel) x n(n-1)/2 pairs x 14 m; the "
