@@ -384,6 +384,30 @@ def test_two_streams_at_vit_base_vit_huge_widths():
         assert abs(a_ - b_) <= 2e-2 * abs(b_), losses
 
 
+@pytest.mark.parametrize("student,teacher,batch,steps,pipe", [
+    ("vit_base_patch16_224", "vit_huge_patch14_224", 256, 36, False),
+    ("vit_base_patch16_224", "vit_huge_patch14_224", 256, 12, True),
+    ("deit_small_patch16_224", "vit_large_patch16_224", 128, 30, False)])
+def test_wide_students_train_for_many_steps_at_the_bench_batch_without_a_health_flag(student, teacher, batch, steps, pipe):
+    """BASELINE configs[4] / configs[3] at their per-GPU batch, as bench.py runs them: captured steps over four cycling
+    synthetic batches with a moving student.  Thousands of wide eigenproblems per step pass through the blocked
+    eigensolver; in round 3 one of them (a rank-deficient Cholesky factor with debris columns) raised NONCONVERGED about
+    once in 30 unpipelined c5 steps.  No health flag, finite losses, the loss goes down."""
+    from basd_amd.train import SyntheticLoader
+    trainer, b0 = _make_preset(student, teacher, batch)
+    batches = [b0] + [next(iter(SyntheticLoader(batch, 224, 1000, 1, "cuda", seed=1234 + 1000 * i))) for i in range(1, 4)]
+    assert trainer.enable_graph(b0, pipeline=pipe), trainer.graph_error
+    assert trainer.two_stream_refused is None
+    losses = []
+    for i in range(steps):
+        loss, _ = trainer.train_step(batches[i % 4], batches[(i + 1) % 4])     # a flag raises BasdLinAlgError here ...
+        losses.append(loss.clone())                # (the captured step returns its static output tensor)
+    trainer.check_health()                                                         # ... or here
+    losses = [float(l) for l in losses]
+    assert all(l == l and l < 1e3 for l in losses), losses
+    assert min(losses[-4:]) < losses[0]
+
+
 def test_a_library_gemm_in_the_teacher_branch_serialises_the_step(monkeypatch):
     """the structural two-stream rule: one library GEMM call site in the teacher branch -> no side stream, no pipelining;
     forcing the overlap in that state is refused"""
