@@ -518,6 +518,15 @@ __device__ __forceinline__ void gemm_epilogue_direct(gf32x4 (&acc)[4][8], const 
 // in two along K across pairs of workgroups (2.5 rounds instead of 3 on fc2 / proj): parking both fp32 halves, the drain,
 // the flag and the 512 KB reload cost the finishing workgroup ~20 us -- more than the half tile saves at K = 768 and
 // about what it saves at K = 3072 (fc2 229 vs 224 us, proj 79 vs 69, qkv 194 vs 176).
+// Where the time goes (ablations of this kernel, timing only, M = 50 432 on a box where the full kernel runs fc1 + GELU /
+// fc2 / qkv / proj in 336 / 238 / 184 / 72 us): without the MFMAs 206 / 197 / 137 / 51 -- the machinery around them is
+// 61 - 83 % of the time; without the LDS fragment reads 264 / 191 / 148 / 60; without the LDS-DMA 295 / 195 / 161 / 63;
+// without the barrier: no change; without the epilogue 208 / 231 / 149 / 56: it costs 38 % of fc1 + GELU (13.9 us per
+// tile: ~5 us for the 128 KB of stores that all 256 CUs issue in the same microseconds -- HBM-write-bound bursts -- and
+// ~9 us of exact-erf GELU, ~21 VALU issue slots per element with its rcp and exp), 19 - 22 % of qkv / proj.  All eight
+// waves reach the epilogue together, so none of it hides under MFMAs; a second accumulator set (to interleave the
+// epilogue of tile t with the K loop of tile t + 1) does not fit 2 waves per SIMD, and two half-size workgroups per CU
+// halve the prefetch depth of the ring (the duo experiment above).
 // Operand addresses are an SGPR base (tile, K step) + a 32-bit per-lane offset that does not depend on the tile: eight
 // VGPRs instead of sixteen 64-bit pointers, and the next tile costs scalar arithmetic only.
 template <int EPI>

@@ -115,6 +115,11 @@ __global__ __launch_bounds__(768) void trinv_blocked_kernel(const double* __rest
   for (int i = tid; i < 16 * nb; i += nt) s_piv[i] = (i < n) ? piv[i] : 0;
   __syncthreads();
   // ---- gather L_p[i, k] = Lw[k * n + piv[i]] (k <= i); dead / padding columns -> identity
+  // (The scattered 8-byte reads fetch 849 MB per 1024 x 192^2 launch for 151 MB of lower-triangle data, PMC.  Measured
+  // in round 3 and rejected: row-contiguous global passes with the permutation done on the LDS side -- inverse
+  // permutation in s_piv, rows of Lw read front to back, rows of the result written front to back -- 0.411 vs 0.365 ms:
+  // with one workgroup per CU (the 156 KB block triangle) the kernel is bound by its own load -> 11 levels -> store
+  // chain, not by the bytes, and the extra LDS passes cost more than the saved fetches bring.)
   const int nblk = nb * (nb + 1) / 2;
   for (int e = tid; e < nblk * 256; e += nt) {
     const int b = e >> 8, r = e & 15, c = (e >> 4) & 15;   // consecutive threads: consecutive rows of a column
