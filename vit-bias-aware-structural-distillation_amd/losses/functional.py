@@ -150,7 +150,6 @@ def _psd_eig_blocked(a64: torch.Tensor):
     x = _blocked_pchol(a64, n_pad)                                       # [b, n_pad(col), n_pad(row)]
     nblk = n_pad // WIDE_BLOCK
     xv = x.view(b, nblk, WIDE_BLOCK, n_pad)
-    rounds = _tournament(nblk, x.device)
     if n_pad <= ops.JACOBI_TALL_ROWS:
         # D_s = 384: a block pair (192 columns x 384 rows) is register-resident in the tall-column Jacobi kernel, so a
         # visit is ONE launch that rotates the actual columns (one inner sweep, no Gram, no pair rotation matrix): the
@@ -185,11 +184,16 @@ def _psd_eig_blocked(a64: torch.Tensor):
             done |= quiet
         xv.copy_(cur[:, restore])
     else:
+        # blocks kept in PAIR order as above: one block permutation per round (the gather that forms the pairs) instead
+        # of a gather and a scatter back into the natural order (147 index kernels of 0.1 ms per c5 step)
+        perms, restore = _tournament_perms(nblk, x.device)
+        cur = xv
         for _ in range(_wide_sweeps(nblk)):
-            for idx in rounds:
-                xp = xv[:, idx].reshape(b * (nblk // 2), 2 * WIDE_BLOCK, n_pad)
+            for perm, _siblings in perms:
+                xp = cur[:, perm].reshape(b * (nblk // 2), 2 * WIDE_BLOCK, n_pad)
                 rot = _pair_rotation(ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True))
-                xv[:, idx] = ops.bgemm_f64(rot, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
+                cur = ops.bgemm_f64(rot, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
+        xv.copy_(cur[:, restore])
     # the sweep counts are fixed (no host sync): verify on the device that the columns ARE orthogonal and raise the
     # NONCONVERGED bit of the health word otherwise (surfaces as BasdLinAlgError at the next status check)
     gram = ops.bgemm_f64(x, x, trans_b=True, symmetric=True)             # [b, n_pad, n_pad] = column Gram of X
