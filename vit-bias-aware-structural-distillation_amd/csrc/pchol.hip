@@ -59,29 +59,35 @@ __device__ __forceinline__ void wave_argmax(double& v, int& idx) {
   v = bv; idx = bi;
 }
 
+// TC = columns per thread, NTC = column groups: <6, 32> covers 192 x 192 with 24 x 32 threads, <7, 28> covers 196 columns
+// (and up to 208 rows) with 26 x 28 = 728 of the 768 threads: the 196-token Gram matrices and cores of the wide students
+// (BASELINE c4 / c5), which otherwise take the global-memory kernel below at 4 x the time.
+template <int TC, int NTC>
 __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict__ a_all, int n, double tol,
                                                         const double* __restrict__ dmax_ref,
                                                         float* __restrict__ w0_all, int ld,
                                                         double* __restrict__ lw_all,
                                                         int32_t* __restrict__ piv_all,
                                                         int32_t* __restrict__ rank_all) {
-  __shared__ __align__(16) double s_c[192];
+  constexpr int NMAX = (TC * NTC + 15) / 16 * 16;    // 192 | 208: rows / columns the thread grid covers
+  constexpr int NQ = (NMAX + 63) / 64;               // diagonal entries per lane of wave 0
+  __shared__ __align__(16) double s_c[NMAX];
   __shared__ double s_pv;
   __shared__ int s_pi;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int tr = tid >> 5, tc = tid & 31;          // tile row / tile column
+  const int tr = tid / NTC, tc = tid - tr * NTC;   // tile row / tile column (threads beyond the grid hold zero tiles)
   const double* A = a_all + (size_t)blockIdx.x * n * n;
   double* Lw = lw_all + (size_t)blockIdx.x * n * n;
   float* W0 = w0_all + (size_t)blockIdx.x * n * ld;
   int32_t* piv = piv_all + (size_t)blockIdx.x * n;
 
-  double R[8][6];
+  double R[8][TC];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int i = 8 * tr + r;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const int j = 6 * tc + c;
+    for (int c = 0; c < TC; ++c) {
+      const int j = TC * tc + c;
       // only the lower triangle of A is read (row >= column): producers that accumulate lower tiles only
       // (basd_token_gram) need no mirroring pass
       R[r][c] = (i < n && j < n) ? (i >= j ? A[(size_t)i * n + j] : A[(size_t)j * n + i]) : 0.0;
@@ -89,20 +95,22 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
   }
   unsigned cdone = 0;                               // bit c: column 6 tc + c was pivoted (or is padding)
 #pragma unroll
-  for (int c = 0; c < 6; ++c)
-    if (6 * tc + c >= n) cdone |= 1u << c;
+  for (int c = 0; c < TC; ++c)
+    if (TC * tc + c >= n) cdone |= 1u << c;
   // wave 0: residual diagonal of rows lane, lane + 64, lane + 128
-  double d[3] = {0.0, 0.0, 0.0};
+  double d[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) d[q] = 0.0;
   unsigned alive = 0;
   if (tid < 64) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int t = lane + 64 * q;
       if (t < n) { d[q] = A[(size_t)t * n + t]; alive |= 1u << q; }
     }
     double v = -1.0e300; int idx = n;
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NQ; ++q)
       if (((alive >> q) & 1) && d[q] > v) { v = d[q]; idx = lane + 64 * q; }
     wave_argmax(v, idx);
     if (tid == 0) { s_pv = v; s_pi = idx; }
@@ -118,51 +126,60 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
     if (!(pval > tol * dmax0) || !(pval > 0.0)) { rank = k; break; }
     if (tr == (p >> 3)) {                                       // owners of row p publish it
       const int pr = p & 7;
-      double v[6];
+      double v[TC];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] = R[0][c];
+      for (int c = 0; c < TC; ++c) v[c] = R[0][c];
 #pragma unroll
       for (int r = 1; r < 8; ++r)
         if (pr == r) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) v[c] = R[r][c];
+          for (int c = 0; c < TC; ++c) v[c] = R[r][c];
         }
       const double lkk = sqrt(pval);
       const double rinv = 1.0 / lkk;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
+      for (int c = 0; c < TC; ++c) {
         double cj = ((cdone >> c) & 1) ? 0.0 : v[c] * rinv;
-        if (6 * tc + c == p) cj = lkk;
-        s_c[6 * tc + c] = cj;
+        if (TC * tc + c == p) cj = lkk;
+        if (TC * tc + c < NMAX) s_c[TC * tc + c] = cj;
       }
     }
     {
-      const int q = p / 6;
-      if (tc == q) cdone |= 1u << (p - 6 * q);
+      const int q = p / TC;
+      if (tc == q) cdone |= 1u << (p - TC * q);
     }
     lds_barrier();                                              // (B) column k visible
-    double cr[8], cc[6];
+    double cr[8], cc[TC];
+    const int r0 = 8 * tr < NMAX - 8 ? 8 * tr : NMAX - 8;
     {
-      const double2* pr2 = reinterpret_cast<const double2*>(s_c + 8 * tr);
-      const double2* pc2 = reinterpret_cast<const double2*>(s_c + 6 * tc);
+      const double2* pr2 = reinterpret_cast<const double2*>(s_c + r0);
+      const int c0 = (TC * tc < NMAX - TC) ? TC * tc : NMAX - TC;      // (threads beyond the grid: any valid address)
+      if (TC % 2 == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const double2 t2 = pr2[r]; cr[2 * r] = t2.x; cr[2 * r + 1] = t2.y; }
+        for (int r = 0; r < 4; ++r) { const double2 t2 = pr2[r]; cr[2 * r] = t2.x; cr[2 * r + 1] = t2.y; }
+      }
+      if (TC % 2 == 0) {
+        const double2* pc2 = reinterpret_cast<const double2*>(s_c + c0);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { const double2 t2 = pc2[c]; cc[2 * c] = t2.x; cc[2 * c + 1] = t2.y; }
+        for (int c = 0; c < TC / 2; ++c) { const double2 t2 = pc2[c]; cc[2 * c] = t2.x; cc[2 * c + 1] = t2.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < TC; ++c) cc[c] = s_c[c0 + c];
+      }
     }
     if (tid < 64) {
       double v = -1.0e300; int idx = n;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int t = lane + 64 * q;
-        const double c = s_c[t < 192 ? t : 0];
+        const double c = s_c[t < NMAX ? t : 0];
         d[q] = fma(-c, c, d[q]);
         if (t == p) alive &= ~(1u << q);
         if (((alive >> q) & 1) && d[q] > v) { v = d[q]; idx = t; }
       }
       wave_argmax(v, idx);
       if (tid == 0) { s_pv = v; s_pi = idx; piv[k] = p; }
-    } else if (tid < 256) {
+    } else if (tid < 64 + NMAX) {
       const int t = tid - 64;
       if (t < n) {
         const double c = s_c[t];
@@ -170,10 +187,25 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
         W0[(size_t)k * ld + t] = (float)c;
       }
     }
+    if (TC % 2 == 0) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+      for (int r = 0; r < 8; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) R[r][c] = fma(-cr[r], cc[c], R[r][c]);
+        for (int c = 0; c < TC; ++c) R[r][c] = fma(-cr[r], cc[c], R[r][c]);
+    } else {
+      // 56 residual + 7 column values per thread leave no room for the eight row values: they are read pair by pair
+      // (the scheduling barrier keeps the compiler from hoisting all four reads)
+#pragma unroll
+      for (int r2 = 0; r2 < 4; ++r2) {
+        const double2 t2 = *reinterpret_cast<const double2*>(s_c + r0 + 2 * r2);
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+          R[2 * r2][c] = fma(-t2.x, cc[c], R[2 * r2][c]);
+          R[2 * r2 + 1][c] = fma(-t2.y, cc[c], R[2 * r2 + 1][c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
   // ---- zero the steps beyond the numerical rank and the padding columns; complete the permutation
   for (int e = tid; e < (n - rank) * n; e += blockDim.x) {
@@ -189,7 +221,7 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
   if (tid < 64) {
     int base = rank;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const bool al = (alive >> q) & 1;
       const unsigned long long m = __ballot(al);
       if (al) piv[base + __popcll(m & ((1ull << lane) - 1ull))] = lane + 64 * q;
@@ -342,9 +374,12 @@ extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, con
   if (n < 1 || n > 256 || ld < n || ld > 256 + 64)
     return fail(BASD_ERR_SHAPE, "pchol_f64: bad shape n=%d ld=%d", n, ld);
   if (n <= 192) {
-    hipLaunchKernelGGL(pchol_reg_kernel, dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0, ld,
-                       lwork, piv, rank);
-  } else {   // global-memory (L2-resident) left-looking kernel for 192 < n <= 256
+    hipLaunchKernelGGL((pchol_reg_kernel<6, 32>), dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0,
+                       ld, lwork, piv, rank);
+  } else if (n <= 196) {   // the 196 tokens of the wide students
+    hipLaunchKernelGGL((pchol_reg_kernel<7, 28>), dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0,
+                       ld, lwork, piv, rank);
+  } else {   // global-memory (L2-resident) left-looking kernel for 196 < n <= 256
     hipLaunchKernelGGL(pchol_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0,
                        ld, lwork, piv, rank);
   }
