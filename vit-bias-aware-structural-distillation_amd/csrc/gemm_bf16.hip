@@ -527,6 +527,9 @@ __device__ __forceinline__ void gemm_epilogue_direct(gf32x4 (&acc)[4][8], const 
 // waves reach the epilogue together, so none of it hides under MFMAs; a second accumulator set (to interleave the
 // epilogue of tile t with the K loop of tile t + 1) does not fit 2 waves per SIMD, and two half-size workgroups per CU
 // halve the prefetch depth of the ring (the duo experiment above).
+// (Starting XCD x of the first chunk x * 1 000 .. 10 000 cycles late, so that the XCDs reach their epilogues at different
+// times without parking anything: no gain -- fc1 + GELU 331 - 351 vs 334 - 342 us, qkv 185 vs 185, fc2 / proj 5 - 30 %
+// slower -- so the epilogue's cost is per CU, not contention for HBM writes.)
 // Operand addresses are an SGPR base (tile, K step) + a 32-bit per-lane offset that does not depend on the tile: eight
 // VGPRs instead of sixteen 64-bit pointers, and the next tile costs scalar arithmetic only.
 template <int EPI>
