@@ -122,12 +122,22 @@ int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_b
 int basd_pchol_f64(const double* a, int batch, int n, double tol, const double* dmax_ref,
                    float* w0, int ld, double* lwork, int32_t* piv, int32_t* rank,
                    void* stream);
+/* The same with a problem mask: skip (device int32 [batch], nullable): skip[b] != 0 leaves every output of matrix b
+ * untouched (its workgroup returns at once).  For batched pipelines whose set of live problems is known on the DEVICE
+ * only -- the block pairs of the wide students' eigensolver that contain an all-zero block (rank-masked
+ * principal-angle problems, src/losses/layer_selector.py:84-92): no host sync, no re-packing of the batch. */
+int basd_pchol_f64_masked(const double* a, int batch, int n, double tol, const double* dmax_ref,
+                          float* w0, int ld, double* lwork, int32_t* piv, int32_t* rank,
+                          const int32_t* skip, void* stream);
 
 /* Inverse of the pivoted Cholesky factor left by basd_pchol_f64, fp64, packed triangle in LDS:
  * out[b] = L_p^-1 P  ([n, n] row-major; P = pivot permutation, L_p = P L lower triangular), so
  * out @ M == L_p^-1 (P M) for M with rows in ORIGINAL order.  Rows >= rank[b] are zero. */
 int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank, int batch, int n,
                    double* out, void* stream);
+/* skip[b] != 0: out[b] untouched (see basd_pchol_f64_masked) */
+int basd_trinv_f64_masked(const double* lwork, const int32_t* piv, const int32_t* rank, int batch, int n,
+                          double* out, const int32_t* skip, void* stream);
 
 /* One-sided (Hestenes) Jacobi in LDS on `batch` column-major matrices
  * w[b]: n_cols columns of `ld` floats, first m_rows rows significant
@@ -144,6 +154,8 @@ int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank,
  * block only (rank-masked principal-angle problems, no host sync on the ranks).  active[b] < 0 skips matrix b
  * altogether (w, sigma untouched, sweeps[b] = 0; register-resident single-matrix kernels, i.e. batch < 512 or tall /
  * single-mailbox shapes): converged matrices of a block tournament cost a 5 us launch instead of a sweep.
+ * active_rows == 2 declares `active` a pure MASK -- every entry is either < 0 (skip) or n_cols (solve completely) --
+ * which the block-ordering kernel of the large batches honours too.
  * status (optional, device int32 word, may be NULL): BASD_STATUS_NONCONVERGED / BASD_STATUS_NONFINITE are OR-ed in.
  * Requires n_cols <= 256, ld % 4 == 0 and either n_cols * ld * 4 + 4096 <= 160 KiB (matrix resident in LDS) or the
  * register-resident forms: m_rows <= 224, or m_rows <= 384 with n_cols <= 192 (tall block pairs; with max_sweeps = 1
@@ -213,6 +225,11 @@ int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int tr
                    const void* b, int b_dtype, int64_t b_stride, int ldb, int trans_b,
                    void* c, int c_dtype, int64_t c_stride, int ldc,
                    int batch, int M, int N, int K, int symmetric, void* stream);
+/* skip[b] != 0: c[b] untouched (see basd_pchol_f64_masked) */
+int basd_bgemm_f64_masked(const void* a, int a_dtype, int64_t a_stride, int lda, int trans_a,
+                          const void* b, int b_dtype, int64_t b_stride, int ldb, int trans_b,
+                          void* c, int c_dtype, int64_t c_stride, int ldc,
+                          int batch, int M, int N, int K, int symmetric, const int32_t* skip, void* stream);
 
 /* ViT linear layer on the bf16 matrix cores with a fused epilogue (timm nn.Linear + nn.GELU of the blocks; reference
  * call sites src/models/teacher.py:212 and src/training/trainer.py:33; with w := W^T also the input gradient

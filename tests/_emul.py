@@ -67,8 +67,24 @@ def token_gram(x, proj, mirror=True, out=None):
     return g, z.sum(0)
 
 
-def pchol(a, tol=1e-13, dmax_ref=None):
+def _poison(skip, *outs):
+    """masked problems (``skip[b] != 0``) leave their outputs unspecified on the device: NaN / garbage here, so that host
+    logic which reads them fails loudly"""
+    if skip is not None:
+        m = skip != 0
+        for o in outs:
+            if o.is_floating_point():
+                o[m] = float("nan")
+            else:
+                o[m] = -12345
+    return outs[0] if len(outs) == 1 else outs
+
+
+def pchol(a, tol=1e-13, dmax_ref=None, skip=None):
     """Batched (vectorised over the batch) diagonal-pivoted Cholesky with the kernel's output contract."""
+    if skip is not None:
+        a = torch.where((skip != 0).view(-1, 1, 1), torch.eye(a.shape[-1], dtype=a.dtype).expand_as(a), a)
+        return _poison(skip, *pchol(a, tol, dmax_ref))
     a = a.double()
     a = torch.tril(a) + torch.tril(a, -1).transpose(-1, -2)     # only the lower triangle is read
     batch, n, _ = a.shape
@@ -123,7 +139,11 @@ def jacobi_svd(w, m_rows, norm_rows=None, *, tol=None, max_sweeps=40, sort=True,
     if norm_rows is None:
         norm_rows = m_rows
     sigma = torch.zeros(batch, n_cols, dtype=torch.float32)
-    if not bool(torch.isfinite(w).all()):
+    live = torch.ones(batch, dtype=torch.bool) if active is None else (active.view(-1) >= 0)
+    if active is not None and int(active_rows) == 2:
+        assert bool(((active.view(-1) < 0) | (active.view(-1) == n_cols)).all()), "active_rows == 2: a pure mask"
+        active_rows = False
+    if not bool(torch.isfinite(w[live]).all()):
         _STATUS[0] |= 2
         w.copy_(torch.nan_to_num(w, nan=0.0, posinf=0.0, neginf=0.0))
         sigma.fill_(float("nan"))
@@ -252,16 +272,25 @@ def lerp_(y, z, w):
     y.add_(z - y, alpha=w)
 
 
-def bgemm_f64(a, b, *, trans_a=False, trans_b=False, out_dtype=torch.float64, symmetric=False):
+def bgemm_f64(a, b, *, trans_a=False, trans_b=False, out_dtype=torch.float64, symmetric=False, skip=None):
     a, b = a.double(), b.double()
+    if skip is not None:            # masked problems may hold unspecified inputs
+        a, b = torch.nan_to_num(a), torch.nan_to_num(b)
     if trans_a:
         a = a.transpose(1, 2)
     if trans_b:
         b = b.transpose(1, 2)
-    return (a @ b).to(out_dtype)
+    return _poison(skip, (a @ b).to(out_dtype))
 
 
-def trinv(lwork, piv, rank):
+def trinv(lwork, piv, rank, skip=None):
+    if skip is not None:
+        m = skip != 0
+        lwork, piv, rank = lwork.clone(), piv.clone(), rank.clone()
+        lwork[m] = torch.eye(lwork.shape[-1], dtype=lwork.dtype)
+        piv[m] = torch.arange(piv.shape[-1], dtype=piv.dtype)
+        rank[m] = 0
+        return _poison(skip, trinv(lwork, piv, rank))
     batch, n, _ = lwork.shape
     out = torch.zeros(batch, n, n, dtype=torch.float64)
     for b in range(batch):

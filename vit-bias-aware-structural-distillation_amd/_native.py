@@ -22,7 +22,7 @@ EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_flag_if_exceeds_f64", "basd_angle_weights", "basd_ce_uwso",
     "basd_procrustes_workspace_bytes", "basd_procrustes_fwd", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
-    "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
+    "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_bgemm_f64_masked", "basd_trinv_f64_masked", "basd_pchol_f64_masked", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
     "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_gemm_bf16x3_f32", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
 )
@@ -36,7 +36,9 @@ _SIGNATURES = {
     "basd_token_gram": (_P, _I, _I64, _I, _I, _I64, _P, _I, _P, _P, _P),
     "basd_token_gram_bf16x3": (_P, _I64, _I, _I, _I64, _P, _I, _P, _P, _P),
     "basd_pchol_f64": (_P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P),
+    "basd_pchol_f64_masked": (_P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P),
     "basd_trinv_f64": (_P, _P, _P, _I, _I, _P, _P),
+    "basd_trinv_f64_masked": (_P, _P, _P, _I, _I, _P, _P, _P),
     "basd_jacobi_svd": (_P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _I, _P, _P),
     "basd_mp_rank": (_P, _I, _I, _I64, _I, _I, _P, _P, _P),
     "basd_flag_if_exceeds_f64": (_P, _I64, _D, _I, _P, _P),
@@ -49,6 +51,7 @@ _SIGNATURES = {
     "basd_ce_uwso": (_P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P),
     "basd_transpose_bf16_table": (_P, _P, _P, _I, _P),
     "basd_bgemm_f64": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P),
+    "basd_bgemm_f64_masked": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P, _P),
     "basd_wgrad_bf16": (_P, _P, _I64, _I, _I, _P, _P, _P),
     "basd_wgrad_workspace_bytes": (_I64, _I, _I),
     "basd_wgrad_bf16_ws": (_P, _P, _I64, _I, _I, _P, _P, _P, _I64, _P),
@@ -326,10 +329,19 @@ def token_gram(x: torch.Tensor, proj: torch.Tensor, mirror: bool = True, out=Non
     return (_mirror_lower(gram) if mirror else gram), colsum
 
 
-def pchol(a: torch.Tensor, tol: float = 1e-13, dmax_ref: torch.Tensor | None = None):
+def _skip_mask(skip, batch: int):
+    """int32 [batch] device mask of the *_masked entries (non-zero = leave the problem's outputs untouched) | None"""
+    if skip is None:
+        return None
+    assert skip.dtype == torch.int32 and skip.numel() == batch and skip.is_contiguous()
+    return skip
+
+
+def pchol(a: torch.Tensor, tol: float = 1e-13, dmax_ref: torch.Tensor | None = None, skip: torch.Tensor | None = None):
     """a [batch, n, n] f64 PSD -> (w0 [batch, n, ld] f32, lwork [batch, n, n] f64, piv, rank).
     ``dmax_ref`` (fp64 [batch], optional): the stop test is ``pivot > tol * dmax_ref[b]`` instead of relative to the
-    matrix's own largest diagonal entry (panels of a blocked factorisation)."""
+    matrix's own largest diagonal entry (panels of a blocked factorisation).  ``skip`` (int32 [batch] on the device,
+    optional): the outputs of problems with a non-zero entry are left uninitialised (basd_pchol_f64_masked)."""
     _need_cuda(a)
     a = a.contiguous()
     if dmax_ref is not None:
@@ -341,8 +353,9 @@ def pchol(a: torch.Tensor, tol: float = 1e-13, dmax_ref: torch.Tensor | None = N
     lwork = torch.empty(batch, n, n, dtype=torch.float64, device=a.device)
     piv = torch.empty(batch, n, dtype=torch.int32, device=a.device)
     rank = torch.empty(batch, dtype=torch.int32, device=a.device)
-    _check(lib().basd_pchol_f64(_ptr(a), batch, n, ctypes.c_double(tol), _ptr(dmax_ref), _ptr(w0), ld, _ptr(lwork),
-                                _ptr(piv), _ptr(rank), _stream()), "basd_pchol_f64")
+    _check(lib().basd_pchol_f64_masked(_ptr(a), batch, n, ctypes.c_double(tol), _ptr(dmax_ref), _ptr(w0), ld, _ptr(lwork),
+                                       _ptr(piv), _ptr(rank), _ptr(_skip_mask(skip, batch)), _stream()),
+           "basd_pchol_f64_masked")
     return w0, lwork, piv, rank
 
 
@@ -629,9 +642,9 @@ def transpose_table(master: torch.Tensor, out: torch.Tensor, table) -> None:
 
 
 def bgemm_f64(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
-              out_dtype=torch.float64, symmetric: bool = False) -> torch.Tensor:
+              out_dtype=torch.float64, symmetric: bool = False, skip: torch.Tensor | None = None) -> torch.Tensor:
     """Batched op(a) @ op(b) with fp64 accumulation; a, b [batch, r, c] fp32/fp64 contiguous.  An operand with batch
-    1 is broadcast over the other one's batch (batch stride 0: no copies)."""
+    1 is broadcast over the other one's batch (batch stride 0: no copies).  ``skip``: see ``pchol``."""
     _need_cuda(a, b)
     a, b = a.contiguous(), b.contiguous()
     code = {torch.float32: DTYPE_F32, torch.float64: DTYPE_F64}
@@ -643,20 +656,21 @@ def bgemm_f64(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_
     i64 = ctypes.c_int64
     sa = a.shape[1] * a.shape[2] if a.shape[0] == batch else 0
     sb = b.shape[1] * b.shape[2] if b.shape[0] == batch else 0
-    _check(lib().basd_bgemm_f64(_ptr(a), code[a.dtype], i64(sa), a.shape[2], int(trans_a),
-                                _ptr(b), code[b.dtype], i64(sb), b.shape[2], int(trans_b),
-                                _ptr(c), code[out_dtype], i64(M * N), N, batch, M, N, K, int(symmetric), _stream()),
-           "basd_bgemm_f64")
+    _check(lib().basd_bgemm_f64_masked(_ptr(a), code[a.dtype], i64(sa), a.shape[2], int(trans_a),
+                                       _ptr(b), code[b.dtype], i64(sb), b.shape[2], int(trans_b),
+                                       _ptr(c), code[out_dtype], i64(M * N), N, batch, M, N, K, int(symmetric),
+                                       _ptr(_skip_mask(skip, batch)), _stream()),
+           "basd_bgemm_f64_masked")
     return c
 
 
-def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
-    """(lwork, piv, rank) from pchol -> L_p^-1 P  [batch, n, n] fp64 (see basd_trinv_f64)."""
+def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor, skip: torch.Tensor | None = None) -> torch.Tensor:
+    """(lwork, piv, rank) from pchol -> L_p^-1 P  [batch, n, n] fp64 (see basd_trinv_f64).  ``skip``: see ``pchol``."""
     _need_cuda(lwork, piv, rank)
     batch, n, _ = lwork.shape
     out = torch.empty(batch, n, n, dtype=torch.float64, device=lwork.device)
-    _check(lib().basd_trinv_f64(_ptr(lwork.contiguous()), _ptr(piv.contiguous()), _ptr(rank.contiguous()), batch, n,
-                                _ptr(out), _stream()), "basd_trinv_f64")
+    _check(lib().basd_trinv_f64_masked(_ptr(lwork.contiguous()), _ptr(piv.contiguous()), _ptr(rank.contiguous()), batch, n,
+                                       _ptr(out), _ptr(_skip_mask(skip, batch)), _stream()), "basd_trinv_f64_masked")
     return out
 
 

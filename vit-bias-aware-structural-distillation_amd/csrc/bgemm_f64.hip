@@ -66,12 +66,13 @@ template <typename TA, typename TB, typename TC>
 __global__ __launch_bounds__(256) void bgemm_f64_kernel(const TA* __restrict__ a, int64_t sa, int lda, int ta,
                                                         const TB* __restrict__ b, int64_t sb, int ldb, int tb,
                                                         TC* __restrict__ c, int64_t sc, int ldc, int M, int N,
-                                                        int K, int sym, int batch) {
+                                                        int K, int sym, int batch, const int32_t* __restrict__ skip) {
   __shared__ double As[BK * BLD];
   __shared__ double Bs[BK * BLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int m0, n0, mat;
   if (!tile_of_block(M, N, batch, m0, n0, mat)) return;
+  if (skip != nullptr && skip[mat] != 0) return;   // masked problem: its output is left untouched
   if (sym && n0 > m0) return;   // C = X X^T: lower tiles only, mirrored on store
   const TA* A = a + (size_t)mat * sa;
   const TB* B = b + (size_t)mat * sb;
@@ -172,12 +173,13 @@ template <typename TA, typename TB, typename TC, int TRA, int TRB>
 __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restrict__ a, int64_t sa, int lda,
                                                              const TB* __restrict__ b, int64_t sb, int ldb,
                                                              TC* __restrict__ c, int64_t sc, int ldc, int M, int N,
-                                                             int K, int sym, int batch) {
+                                                             int K, int sym, int batch, const int32_t* __restrict__ skip) {
   __shared__ __align__(16) double As[2][BK * BLD];
   __shared__ __align__(16) double Bs[2][BK * BLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int m0, n0, mat;
   if (!tile_of_block(M, N, batch, m0, n0, mat)) return;
+  if (skip != nullptr && skip[mat] != 0) return;   // masked problem: its output is left untouched
   if (sym && n0 > m0) return;
   const TA* A = a + (size_t)mat * sa;
   const TB* B = b + (size_t)mat * sb;
@@ -242,11 +244,12 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
 
 template <typename TA, typename TB, typename TC>
 static void launch_bgemm_fast(const void* a, int64_t sa, int lda, int ta, const void* b, int64_t sb, int ldb, int tb,
-                              void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, hipStream_t st) {
+                              void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, const int32_t* skip,
+                              hipStream_t st) {
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * ((N + BT - 1) / BT) * ((M + BT - 1) / BT)));
 #define BASD_BGF(TRA, TRB)                                                                                   \
   hipLaunchKernelGGL((bgemm_f64_fast_kernel<TA, TB, TC, TRA, TRB>), grid, dim3(256), 0, st, (const TA*)a, sa, lda, \
-                     (const TB*)b, sb, ldb, (TC*)c, sc, ldc, M, N, K, sym, batch)
+                     (const TB*)b, sb, ldb, (TC*)c, sc, ldc, M, N, K, sym, batch, skip)
   if (ta) { if (tb) BASD_BGF(1, 1); else BASD_BGF(1, 0); }
   else    { if (tb) BASD_BGF(0, 1); else BASD_BGF(0, 0); }
 #undef BASD_BGF
@@ -254,10 +257,11 @@ static void launch_bgemm_fast(const void* a, int64_t sa, int lda, int ta, const 
 
 template <typename TA, typename TB, typename TC>
 static void launch_bgemm(const void* a, int64_t sa, int lda, int ta, const void* b, int64_t sb, int ldb, int tb,
-                         void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, hipStream_t st) {
+                         void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, const int32_t* skip,
+                         hipStream_t st) {
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * ((N + BT - 1) / BT) * ((M + BT - 1) / BT)));
   hipLaunchKernelGGL((bgemm_f64_kernel<TA, TB, TC>), grid, dim3(256), 0, st, (const TA*)a, sa, lda, ta,
-                     (const TB*)b, sb, ldb, tb, (TC*)c, sc, ldc, M, N, K, sym, batch);
+                     (const TB*)b, sb, ldb, tb, (TC*)c, sc, ldc, M, N, K, sym, batch, skip);
 }
 
 }  // namespace basd
@@ -265,6 +269,14 @@ static void launch_bgemm(const void* a, int64_t sa, int lda, int ta, const void*
 extern "C" int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int lda, int trans_a, const void* b,
                               int b_dtype, int64_t b_stride, int ldb, int trans_b, void* c, int c_dtype,
                               int64_t c_stride, int ldc, int batch, int M, int N, int K, int symmetric, void* stream) {
+  return basd_bgemm_f64_masked(a, a_dtype, a_stride, lda, trans_a, b, b_dtype, b_stride, ldb, trans_b, c, c_dtype, c_stride,
+                               ldc, batch, M, N, K, symmetric, nullptr, stream);
+}
+
+extern "C" int basd_bgemm_f64_masked(const void* a, int a_dtype, int64_t a_stride, int lda, int trans_a, const void* b,
+                                     int b_dtype, int64_t b_stride, int ldb, int trans_b, void* c, int c_dtype,
+                                     int64_t c_stride, int ldc, int batch, int M, int N, int K, int symmetric,
+                                     const int32_t* skip, void* stream) {
   using namespace basd;
   if (batch <= 0 || M <= 0 || N <= 0) return BASD_OK;
   if (symmetric && M != N) return fail(BASD_ERR_SHAPE, "bgemm_f64: symmetric needs M == N");
@@ -279,8 +291,8 @@ extern "C" int basd_bgemm_f64(const void* a, int a_dtype, int64_t a_stride, int 
                        a_stride % 4 == 0 && b_stride % 4 == 0 && ((uintptr_t)a & 31) == 0 && ((uintptr_t)b & 31) == 0;
 #define BASD_BG(TA, TB, TC)                                                                                          \
   do {                                                                                                               \
-    if (aligned) launch_bgemm_fast<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, st); \
-    else launch_bgemm<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, st); \
+    if (aligned) launch_bgemm_fast<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, skip, st); \
+    else launch_bgemm<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, skip, st); \
   } while (0)
   switch (key) {
     case 2: BASD_BG(float, float, double); break;      // f32 x f32 -> f64

@@ -523,8 +523,13 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
 template <int MAXCH>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void jacobi_blk_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
-    float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status) {
+    float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status,
+    const int32_t* __restrict__ skip) {
   extern __shared__ __align__(16) float lds[];
+  if (skip != nullptr && skip[blockIdx.x] < 0) {   // masked problem (active_rows == 2): nothing is read or written
+    if (sweeps_out && threadIdx.x == 0) sweeps_out[blockIdx.x] = 0;
+    return;
+  }
   constexpr int LDC = 32 * MAXCH;                  // one column in the mailbox
   constexpr int LDB = 2 * LDC;                     // one block
   const int tid = threadIdx.x;
@@ -805,7 +810,10 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   }
   // (the block ordering also wins on small batches: 1.06 vs 1.27 ms at 48 matrices of 192^2, 1.27 vs 1.39 at 256,
   // equal at 4 - 24: measured in round 3; before, it was only taken from 512 matrices up)
-  if (active == nullptr && batch >= 32 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
+  // active_rows == 2: `active` is a MASK -- entries are either < 0 (skip the matrix) or n_cols (solve it completely)
+  const bool mask_only = active != nullptr && active_rows == 2;
+  if (mask_only) active_rows = 0;
+  if ((active == nullptr || mask_only) && batch >= 32 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
     // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
     const int nbk = (n_cols + 1) / 2, slots = (nbk + 1) / 2;
     const int threads_b = ((slots * 8 + 63) / 64) * 64;
@@ -814,7 +822,7 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   do {                                                                                               \
     allow_full_lds((const void*)jacobi_blk_kernel<MC>);                                              \
     hipLaunchKernelGGL((jacobi_blk_kernel<MC>), dim3(batch), dim3(threads_b), lds_b, st, w, batch, m_rows, n_cols, \
-                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status);                 \
+                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status, active);         \
   } while (0)
     if (oe_ch == 2) BASD_LAUNCH_BLK(2);
     else if (oe_ch == 4) BASD_LAUNCH_BLK(4);

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(768) void pchol_reg_kernel(const double* __restrict
                                                         float* __restrict__ w0_all, int ld,
                                                         double* __restrict__ lw_all,
                                                         int32_t* __restrict__ piv_all,
-                                                        int32_t* __restrict__ rank_all) {
+                                                        int32_t* __restrict__ rank_all, const int32_t* __restrict__ skip) {
+  if (skip != nullptr && skip[blockIdx.x] != 0) return;       // masked problem: outputs left untouched
   constexpr int NMAX = (TC * NTC + 15) / 16 * 16;    // 192 | 208: rows / columns the thread grid covers
   constexpr int NQ = (NMAX + 63) / 64;               // diagonal entries per lane of wave 0
   __shared__ __align__(16) double s_c[NMAX];
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(1024) void pchol_kernel(const double* __restrict__ 
                                                      float* __restrict__ w0_all, int ld,
                                                      double* __restrict__ lw_all,
                                                      int32_t* __restrict__ piv_all,
-                                                     int32_t* __restrict__ rank_all) {
+                                                     int32_t* __restrict__ rank_all, const int32_t* __restrict__ skip) {
+  if (skip != nullptr && skip[blockIdx.x] != 0) return;       // masked problem: outputs left untouched
   __shared__ double s_d[256];
   __shared__ double s_prow[256];
   __shared__ double s_part[4][256];
@@ -369,19 +371,25 @@ __global__ __launch_bounds__(1024) void mp_rank_kernel(const float* __restrict__
 
 extern "C" int basd_pchol_f64(const double* a, int batch, int n, double tol, const double* dmax_ref, float* w0, int ld,
                               double* lwork, int32_t* piv, int32_t* rank, void* stream) {
+  return basd_pchol_f64_masked(a, batch, n, tol, dmax_ref, w0, ld, lwork, piv, rank, nullptr, stream);
+}
+
+extern "C" int basd_pchol_f64_masked(const double* a, int batch, int n, double tol, const double* dmax_ref, float* w0,
+                                     int ld, double* lwork, int32_t* piv, int32_t* rank, const int32_t* skip,
+                                     void* stream) {
   using namespace basd;
   if (batch <= 0) return BASD_OK;
   if (n < 1 || n > 256 || ld < n || ld > 256 + 64)
     return fail(BASD_ERR_SHAPE, "pchol_f64: bad shape n=%d ld=%d", n, ld);
   if (n <= 192) {
     hipLaunchKernelGGL((pchol_reg_kernel<6, 32>), dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0,
-                       ld, lwork, piv, rank);
+                       ld, lwork, piv, rank, skip);
   } else if (n <= 196) {   // the 196 tokens of the wide students
     hipLaunchKernelGGL((pchol_reg_kernel<7, 28>), dim3(batch), dim3(768), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0,
-                       ld, lwork, piv, rank);
+                       ld, lwork, piv, rank, skip);
   } else {   // global-memory (L2-resident) left-looking kernel for 196 < n <= 256
     hipLaunchKernelGGL(pchol_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, a, n, tol, dmax_ref, w0,
-                       ld, lwork, piv, rank);
+                       ld, lwork, piv, rank, skip);
   }
   return check_launch("pchol_f64");
 }

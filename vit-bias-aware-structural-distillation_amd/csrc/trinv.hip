@@ -21,7 +21,8 @@ __device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }
 __global__ __launch_bounds__(768) void trinv_kernel(const double* __restrict__ lw_all,
                                                     const int32_t* __restrict__ piv_all,
                                                     const int32_t* __restrict__ rank_all, int n,
-                                                    double* __restrict__ out_all) {
+                                                    double* __restrict__ out_all, const int32_t* __restrict__ skip) {
+  if (skip != nullptr && skip[blockIdx.x] != 0) return;       // masked problem: output left untouched
   extern __shared__ __align__(16) double X[];          // packed lower triangle
   int* s_piv = reinterpret_cast<int*>(X + (size_t)n * (n + 1) / 2);
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -101,7 +102,8 @@ __device__ __forceinline__ f64x4t blk_mma(const double* __restrict__ X, int a_of
 __global__ __launch_bounds__(768) void trinv_blocked_kernel(const double* __restrict__ lw_all,
                                                             const int32_t* __restrict__ piv_all,
                                                             const int32_t* __restrict__ rank_all, int n,
-                                                            double* __restrict__ out_all) {
+                                                            double* __restrict__ out_all, const int32_t* __restrict__ skip) {
+  if (skip != nullptr && skip[blockIdx.x] != 0) return;       // masked problem: output left untouched
   extern __shared__ __align__(16) double X[];          // lower block triangle, 16 x 16 row-major blocks
   const int nb = (n + 15) >> 4;
   double* s_rd = X + (size_t)nb * (nb + 1) / 2 * 256;  // [16 nb] reciprocal diagonal
@@ -197,6 +199,11 @@ __global__ __launch_bounds__(768) void trinv_blocked_kernel(const double* __rest
 
 extern "C" int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank, int batch, int n,
                               double* out, void* stream) {
+  return basd_trinv_f64_masked(lwork, piv, rank, batch, n, out, nullptr, stream);
+}
+
+extern "C" int basd_trinv_f64_masked(const double* lwork, const int32_t* piv, const int32_t* rank, int batch, int n,
+                                     double* out, const int32_t* skip, void* stream) {
   using namespace basd;
   if (batch <= 0) return BASD_OK;
   const size_t lds = (size_t)n * (n + 1) / 2 * 8 + (size_t)n * 4 + 64;
@@ -207,11 +214,11 @@ extern "C" int basd_trinv_f64(const double* lwork, const int32_t* piv, const int
   if (nb <= 12 && lds_blk <= 160 * 1024) {
     allow_full_lds((const void*)trinv_blocked_kernel);
     hipLaunchKernelGGL(trinv_blocked_kernel, dim3(batch), dim3(768), lds_blk, (hipStream_t)stream, lwork, piv, rank, n,
-                       out);
+                       out, skip);
     return check_launch("trinv_f64 (blocked)");
   }
   // 4 lanes per row, rows strided by 192 per pass: two passes cover n <= 384 (v[2])
   allow_full_lds((const void*)trinv_kernel);
-  hipLaunchKernelGGL(trinv_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, lwork, piv, rank, n, out);
+  hipLaunchKernelGGL(trinv_kernel, dim3(batch), dim3(768), lds, (hipStream_t)stream, lwork, piv, rank, n, out, skip);
   return check_launch("trinv_f64");
 }

@@ -134,7 +134,7 @@ def _blocked_pchol(a64: torch.Tensor, n_pad: int) -> torch.Tensor:
     return x
 
 
-def _psd_eig_blocked(a64: torch.Tensor):
+def _psd_eig_blocked(a64: torch.Tensor, zero_blocks: bool = False):
     """Eigen-decomposition of PSD fp64 matrices [b, n, n] with n > 192 (student widths 384 / 768: BASELINE c4 / c5).
 
     One-sided BLOCK Jacobi on the blocked Cholesky factor X (A = X X^T): the columns form n_pad / 96 blocks; a round
@@ -187,12 +187,30 @@ def _psd_eig_blocked(a64: torch.Tensor):
         # blocks kept in PAIR order as above: one block permutation per round (the gather that forms the pairs) instead
         # of a gather and a scatter back into the natural order (147 index kernels of 0.1 ms per c5 step)
         perms, restore = _tournament_perms(nblk, x.device)
+        npair = nblk // 2
         cur = xv
+        if zero_blocks:
+            # rank-masked problems (the principal-angle Gram matrices of the 768-wide selector have rank k_j ~ 350: four
+            # of their eight column blocks are exact zeros, known on the DEVICE only): a pair with an all-zero block
+            # has nothing to rotate against -- 22 of the 28 pairs of a sweep here.  Such pairs are masked out of every
+            # launch of the visit (`skip`: the workgroups of a masked problem return at once, no host sync, no
+            # re-packing) and keep their blocks; a matrix with ONE non-zero block is visited with its sibling.
+            nz = (xv.abs().amax(dim=(2, 3)) > 0)                       # [b, nblk]: block holds a non-zero column
+            lone = (nz.sum(dim=1) == 1).unsqueeze(1)                    # [b, 1]
         for _ in range(_wide_sweeps(nblk)):
-            for perm, _siblings in perms:
-                xp = cur[:, perm].reshape(b * (nblk // 2), 2 * WIDE_BLOCK, n_pad)
-                rot = _pair_rotation(ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True))
-                cur = ops.bgemm_f64(rot, xp, out_dtype=torch.float32).view(b, nblk, WIDE_BLOCK, n_pad)
+            for perm, siblings in perms:
+                xp = cur[:, perm].reshape(b * npair, 2 * WIDE_BLOCK, n_pad)
+                skip = None
+                if zero_blocks:
+                    nz = nz[:, perm]
+                    nzp = nz.view(b, npair, 2)
+                    work = nzp.all(dim=2) | (lone & nzp.any(dim=2) & siblings.unsqueeze(0))      # [b, npair]
+                    skip = (~work).reshape(-1).to(torch.int32)
+                rot = _pair_rotation(ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True, skip=skip), skip=skip)
+                new = ops.bgemm_f64(rot, xp, out_dtype=torch.float32, skip=skip)
+                if zero_blocks:
+                    new = torch.where(work.reshape(-1, 1, 1), new, xp)
+                cur = new.view(b, nblk, WIDE_BLOCK, n_pad)
         xv.copy_(cur[:, restore])
     # the sweep counts are fixed (no host sync): verify on the device that the columns ARE orthogonal and raise the
     # NONCONVERGED bit of the health word otherwise (surfaces as BasdLinAlgError at the next status check)
@@ -210,7 +228,7 @@ def _psd_eig_blocked(a64: torch.Tensor):
     return sigma, u
 
 
-def _pair_rotation(g: torch.Tensor) -> torch.Tensor:
+def _pair_rotation(g: torch.Tensor, skip: torch.Tensor | None = None) -> torch.Tensor:
     """g = Xp^T Xp [b, k, k] fp64 (Gram of a column-block pair) -> J^T [b, k, k] fp64: row i holds the coefficients of
     output column i over the input columns; Xp J has mutually orthogonal columns sorted by norm, J is orthogonal.
 
@@ -225,17 +243,28 @@ def _pair_rotation(g: torch.Tensor) -> torch.Tensor:
     Output columns beyond the numerical rank of the pair (cancellation noise of dependent columns) are zeroed."""
     ops = get_ops()
     b, k, _ = g.shape
-    _, lw, piv, rank = ops.pchol(g, PCHOL_TOL)                             # lw[b, step, row] = L[row, step]
-    wf = torch.zeros(b, k, ops.jacobi_ld(k), dtype=torch.float32, device=g.device)
-    wf[:, :, :k] = lw.transpose(1, 2)                                      # column r of F = row r of L (entries over steps)
-    ops.jacobi_svd(wf, k)                                                  # F J = W in place, columns sorted by norm
-    l_inv = ops.trinv(lw, piv, rank)                                       # [b, step, row] = L^-1 (rows >= rank zero)
-    rot = ops.bgemm_f64(wf[:, :, :k].contiguous(), l_inv)                  # J^T[i, r] = sum_step W[i, step] L^-1[step, r]
+    if skip is None:
+        _, lw, piv, rank = ops.pchol(g, PCHOL_TOL)                         # lw[b, step, row] = L[row, step]
+        wf = torch.zeros(b, k, ops.jacobi_ld(k), dtype=torch.float32, device=g.device)
+        wf[:, :, :k] = lw.transpose(1, 2)                                  # column r of F = row r of L (entries over steps)
+        ops.jacobi_svd(wf, k)                                              # F J = W in place, columns sorted by norm
+        l_inv = ops.trinv(lw, piv, rank)                                   # [b, step, row] = L^-1 (rows >= rank zero)
+        rot = ops.bgemm_f64(wf[:, :, :k].contiguous(), l_inv)              # J^T[i, r] = sum_step W[i, step] L^-1[step, r]
+    else:
+        # ``skip`` (int32 [b], device): masked problems run through none of the kernels; their rows of the result are
+        # unspecified (the caller keeps the old blocks)
+        _, lw, piv, rank = ops.pchol(g, PCHOL_TOL, skip=skip)
+        wf = torch.zeros(b, k, ops.jacobi_ld(k), dtype=torch.float32, device=g.device)
+        wf[:, :, :k] = lw.transpose(1, 2)
+        mask = torch.where(skip != 0, -1, k).to(torch.int32)               # < 0: skip, k: solve completely
+        ops.jacobi_svd(wf, k, active=mask, active_rows=2)
+        l_inv = ops.trinv(lw, piv, rank, skip=skip)
+        rot = ops.bgemm_f64(wf[:, :, :k].contiguous(), l_inv, skip=skip)
     keep = torch.arange(k, device=g.device).unsqueeze(0) < rank.unsqueeze(1)
     return rot * keep.unsqueeze(-1)
 
 
-def psd_eig(a64: torch.Tensor, lower_only: bool = False):
+def psd_eig(a64: torch.Tensor, lower_only: bool = False, zero_blocks: bool = False):
     """Batched eigen-decomposition of symmetric PSD fp64 matrices [b, n, n]
     (``lower_only``: only the lower triangles are meaningful, e.g. ``token_gram(..., mirror=False)``).
 
@@ -245,7 +274,7 @@ def psd_eig(a64: torch.Tensor, lower_only: bool = False):
     ops = get_ops()
     n = a64.shape[-1]
     if n > WIDE_PANEL:
-        sigma, u = _psd_eig_blocked(a64)
+        sigma, u = _psd_eig_blocked(a64, zero_blocks=zero_blocks)   # zero_blocks: rank-masked input (a hint, not a promise)
         return sigma, u, None
     if not lower_only:
         a64 = 0.5 * (a64 + a64.transpose(-1, -2))
@@ -382,7 +411,7 @@ class _SelectorWeightsFn(torch.autograd.Function):
             # wide students (D_s = 384 / 768): cosines and left singular vectors from the blocked eigen-solver on
             # the fp64 Gram A_bar A_bar^T (zero rows / columns beyond k_j: the blocked Cholesky stops at the rank)
             ab = a_bar.reshape(E * L, D, D)
-            sig, vec, _ = psd_eig(ops.bgemm_f64(ab, ab, trans_b=True, symmetric=True))
+            sig, vec, _ = psd_eig(ops.bgemm_f64(ab, ab, trans_b=True, symmetric=True), zero_blocks=True)
             sig, vec = sig.view(E, L, D), vec.view(E, L, D, D)
             unnormalised = False
         # acos / spectral weighting / softmax over layers and the diagonal of the backward seed in ONE kernel
