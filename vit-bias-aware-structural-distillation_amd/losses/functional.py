@@ -134,84 +134,124 @@ def _blocked_pchol(a64: torch.Tensor, n_pad: int) -> torch.Tensor:
     return x
 
 
+def _tall_tournament(ops, xv: torch.Tensor, done: torch.Tensor) -> torch.Tensor:
+    """Block-Jacobi tournament with DIRECT visits: xv [b, nblk, 96, rows] fp32 (column blocks of X, rows <= 384) -> the
+    same array with mutually orthogonal columns; matrices with ``done[b]`` set are left alone.
+
+    A block pair (192 columns x up to 384 rows) is register-resident in the tall-column Jacobi kernel, so a visit is
+    ONE launch that rotates the actual columns (one inner sweep, no Gram, no pair rotation matrix): the graded accuracy
+    is the kernel's own.  Simulated on graded random-basis spectra: cosines < 1e-7 after 7 outer sweeps of single inner
+    sweeps (21 visits at 4 blocks; the Gram form needs 5 x 3 visits of ~6 launches each).
+    The blocks are kept in PAIR order (the kernel wants the two blocks of a pair contiguous): one block permutation per
+    round takes round r's order to round r + 1's.  A matrix whose every visit of one whole outer sweep reported "no
+    large rotation" (sweeps > 0) is finished: its pairs are skipped from then on (active = -1 costs a 5 us launch slot
+    instead of a 0.3 ms sweep), all on the device -- no host sync.
+    A pair with an all-zero block (columns beyond the numerical rank: the rank-masked principal-angle problems) is
+    skipped too: rotating against zero columns is a no-op, and a round in which every pair of every matrix is skipped
+    costs no sweep at all.  A matrix with ONE non-zero block still needs that block's own columns rotated: it is
+    visited with its sibling."""
+    b, nblk, _, rows = xv.shape
+    perms, restore = _tournament_perms(nblk, xv.device)
+    npair = nblk // 2
+    cur = xv
+    done = done.clone()
+    nz = (xv.abs().amax(dim=(2, 3)) > 0)                             # [b, nblk]: block holds a non-zero column
+    lone = (nz.sum(dim=1) == 1).unsqueeze(1)                          # [b, 1]
+    full_cols = torch.full((b, npair), 2 * WIDE_BLOCK, dtype=torch.int32, device=xv.device)
+    for _ in range(WIDE_DIRECT_SWEEPS):
+        quiet = torch.ones(b, dtype=torch.bool, device=xv.device)
+        for perm, siblings in perms:
+            cur = cur[:, perm].contiguous()                          # [b, nblk, 96, rows], pair p = blocks 2p, 2p + 1
+            nz = nz[:, perm]
+            nzp = nz.view(b, npair, 2)
+            work = (nzp.all(dim=2) | (lone & nzp.any(dim=2) & siblings.unsqueeze(0))) & ~done.unsqueeze(1)
+            act = torch.where(work, full_cols, -1).reshape(-1).contiguous()
+            _, sw = ops.jacobi_svd(cur.view(b * npair, 2 * WIDE_BLOCK, rows), rows, max_sweeps=1, sort=False,
+                                   flag_status=False, active=act)
+            quiet &= (sw.view(b, npair) >= 0).all(dim=1)
+        done |= quiet
+    return cur[:, restore]
+
+
+def _gram_tournament(ops, xv: torch.Tensor, zero_blocks: bool, skip_matrix: torch.Tensor | None) -> torch.Tensor:
+    """Block-Jacobi tournament in the Gram form (pairs taller than 384 rows): per visit G = Xp^T Xp -> J -> Xp J.
+    Blocks kept in PAIR order: one block permutation per round (the gather that forms the pairs) instead of a gather
+    and a scatter back into the natural order.  ``zero_blocks``: rank-masked problems -- a pair with an all-zero block
+    has nothing to rotate against (22 of the 28 pairs of a sweep for the principal-angle problems of the 768-wide
+    selector, rank ~350 of 768; known on the DEVICE only): such pairs, and every pair of a matrix in ``skip_matrix``,
+    are masked out of every launch of the visit (`skip`: the workgroups of a masked problem return at once, no host
+    sync, no re-packing) and keep their blocks; a matrix with ONE non-zero block is visited with its sibling."""
+    b, nblk, _, n_pad = xv.shape
+    perms, restore = _tournament_perms(nblk, xv.device)
+    npair = nblk // 2
+    cur = xv
+    masked = zero_blocks or skip_matrix is not None
+    if masked:
+        nz = (xv.abs().amax(dim=(2, 3)) > 0) if zero_blocks else torch.ones(b, nblk, dtype=torch.bool, device=xv.device)
+        lone = (nz.sum(dim=1) == 1).unsqueeze(1)
+        live = torch.ones(b, 1, dtype=torch.bool, device=xv.device) if skip_matrix is None else ~skip_matrix.unsqueeze(1)
+    for _ in range(_wide_sweeps(nblk)):
+        for perm, siblings in perms:
+            xp = cur[:, perm].reshape(b * npair, 2 * WIDE_BLOCK, n_pad)
+            skip = None
+            if masked:
+                nz = nz[:, perm]
+                nzp = nz.view(b, npair, 2)
+                work = (nzp.all(dim=2) | (lone & nzp.any(dim=2) & siblings.unsqueeze(0))) & live        # [b, npair]
+                skip = (~work).reshape(-1).to(torch.int32)
+            rot = _pair_rotation(ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True, skip=skip), skip=skip)
+            new = ops.bgemm_f64(rot, xp, out_dtype=torch.float32, skip=skip)
+            if masked:
+                new = torch.where(work.reshape(-1, 1, 1), new, xp)
+            cur = new.view(b, nblk, WIDE_BLOCK, n_pad)
+    return cur[:, restore]
+
+
 def _psd_eig_blocked(a64: torch.Tensor, zero_blocks: bool = False):
     """Eigen-decomposition of PSD fp64 matrices [b, n, n] with n > 192 (student widths 384 / 768: BASELINE c4 / c5).
 
     One-sided BLOCK Jacobi on the blocked Cholesky factor X (A = X X^T): the columns form n_pad / 96 blocks; a round
-    of the tournament takes nblk / 2 disjoint block pairs of every matrix, and for each pair
-        G = Xp^T Xp (192 x 192, fp64 MFMA)  ->  J = _pair_rotation(G)  (pivoted Cholesky + LDS-resident Jacobi)
+    of the tournament takes nblk / 2 disjoint block pairs of every matrix.  Up to 384 rows a visit rotates the columns
+    of a pair directly (``_tall_tournament``); beyond that, for each pair
+        G = Xp^T Xp (192 x 192, fp64 MFMA)  ->  J = _pair_rotation(G)  (pivoted Cholesky + Jacobi)
         Xp <- Xp J                          (fp64-accumulated MFMA GEMM, stored fp32)
-    i.e. the 192-column pair is orthogonalised completely and its rotation is applied as a GEMM; the accuracy is that
-    of one-sided Jacobi (relative per column).  The number of outer sweeps is fixed per width (_wide_sweeps): there is
-    no convergence test on the host.  Returns (sigma [b, n] descending, u [b, n, n] rows = eigenvectors)."""
+    (``_gram_tournament``).  The accuracy is that of one-sided Jacobi (relative per column).  The number of outer
+    sweeps is fixed per width: there is no convergence test on the host.
+
+    ``zero_blocks``: the input is rank-masked (the principal-angle Gram matrices A_bar A_bar^T are non-zero in their
+    leading k_j x k_j corner only, k_j = the teacher layer's Marchenko-Pastur rank: ~160 of 384 at c4, ~350 of 768 at
+    c5).  X is then zero outside a corner of the same size.  Which matrices fit which corner is known on the DEVICE only,
+    so both paths are enqueued and each matrix takes exactly one of them through the problem masks of the kernels:
+    matrices whose X fits the SMALL corner (192: one complete Jacobi solve of the 192 x 192 corner; 384 for the
+    768-wide problems: the direct tournament over four blocks, 21 launches) take the small path, the others the general
+    one, whose launches return at once for masked problems (a fully masked launch costs ~5 us).  No host sync, any rank.
+    Returns (sigma [b, n] descending, u [b, n, n] rows = eigenvectors)."""
     ops = get_ops()
     b, n, _ = a64.shape
     n_pad = -(-n // WIDE_PANEL) * WIDE_PANEL
     x = _blocked_pchol(a64, n_pad)                                       # [b, n_pad(col), n_pad(row)]
     nblk = n_pad // WIDE_BLOCK
     xv = x.view(b, nblk, WIDE_BLOCK, n_pad)
-    if n_pad <= ops.JACOBI_TALL_ROWS:
-        # D_s = 384: a block pair (192 columns x 384 rows) is register-resident in the tall-column Jacobi kernel, so a
-        # visit is ONE launch that rotates the actual columns (one inner sweep, no Gram, no pair rotation matrix): the
-        # graded accuracy is the kernel's own.  Simulated on graded random-basis spectra: cosines < 1e-7 after 7 outer
-        # sweeps of single inner sweeps (21 visits; the Gram form needs 5 x 3 visits of ~6 launches each).
-        # The blocks are kept in PAIR order (the kernel wants the two blocks of a pair contiguous): one block
-        # permutation per round takes round r's order to round r + 1's.  A matrix whose every visit of one whole outer
-        # sweep reported "no large rotation" (sweeps > 0) is finished: its pairs are skipped from then on (active = -1
-        # costs a 5 us launch slot instead of a 0.4 ms sweep), all on the device -- no host sync.
-        # A pair with an all-zero block (columns beyond the numerical rank: the rank-masked principal-angle problems
-        # of a 384-wide student have rank ~160, i.e. two of their four blocks) is skipped too: rotating against zero
-        # columns is a no-op, and a round in which every pair of every matrix is skipped costs no sweep at all.  A
-        # matrix with ONE non-zero block still needs that block's own columns rotated: it is visited with its sibling.
-        perms, restore = _tournament_perms(nblk, x.device)
-        npair = nblk // 2
-        cur = xv
-        done = torch.zeros(b, dtype=torch.bool, device=x.device)
-        nz = (xv.abs().amax(dim=(2, 3)) > 0)                         # [b, nblk]: block holds a non-zero column
-        lone = (nz.sum(dim=1) == 1).unsqueeze(1)                      # [b, 1]
-        full_cols = torch.full((b, npair), 2 * WIDE_BLOCK, dtype=torch.int32, device=x.device)
-        for _ in range(WIDE_DIRECT_SWEEPS):
-            quiet = torch.ones(b, dtype=torch.bool, device=x.device)
-            for perm, siblings in perms:
-                cur = cur[:, perm].contiguous()                      # [b, nblk, 96, n_pad], pair p = blocks 2p, 2p + 1
-                nz = nz[:, perm]
-                nzp = nz.view(b, npair, 2)
-                work = (nzp.all(dim=2) | (lone & nzp.any(dim=2) & siblings.unsqueeze(0))) & ~done.unsqueeze(1)
-                act = torch.where(work, full_cols, -1).reshape(-1).contiguous()
-                _, sw = ops.jacobi_svd(cur.view(b * npair, 2 * WIDE_BLOCK, n_pad), n_pad, max_sweeps=1, sort=False,
-                                       flag_status=False, active=act)
-                quiet &= (sw.view(b, npair) >= 0).all(dim=1)
-            done |= quiet
-        xv.copy_(cur[:, restore])
+    tall = n_pad <= ops.JACOBI_TALL_ROWS
+    small = xs_new = None
+    if zero_blocks:
+        corner = 2 * WIDE_BLOCK if tall else ops.JACOBI_TALL_ROWS
+        outside = torch.maximum(x[:, corner:, :].abs().amax(dim=(1, 2)), x[:, :corner, corner:].abs().amax(dim=(1, 2)))
+        small = outside == 0                                             # [b]: X lives in its leading corner
+        xs = x[:, :corner, :corner].contiguous()                         # [b, corner (col), corner (row)]
+        if tall:
+            w = torch.zeros(b, corner, ops.jacobi_ld(corner), dtype=torch.float32, device=x.device)
+            w[:, :, :corner] = xs
+            ops.jacobi_svd(w, corner, sort=False, active=torch.where(small, corner, -1).to(torch.int32), active_rows=2)
+            xs_new = w[:, :, :corner]
+        else:
+            xs_new = _tall_tournament(ops, xs.view(b, corner // WIDE_BLOCK, WIDE_BLOCK, corner), ~small).reshape(b, corner, corner)
+    if tall:
+        xv.copy_(_tall_tournament(ops, xv, small if small is not None else torch.zeros(b, dtype=torch.bool, device=x.device)))
     else:
-        # blocks kept in PAIR order as above: one block permutation per round (the gather that forms the pairs) instead
-        # of a gather and a scatter back into the natural order (147 index kernels of 0.1 ms per c5 step)
-        perms, restore = _tournament_perms(nblk, x.device)
-        npair = nblk // 2
-        cur = xv
-        if zero_blocks:
-            # rank-masked problems (the principal-angle Gram matrices of the 768-wide selector have rank k_j ~ 350: four
-            # of their eight column blocks are exact zeros, known on the DEVICE only): a pair with an all-zero block
-            # has nothing to rotate against -- 22 of the 28 pairs of a sweep here.  Such pairs are masked out of every
-            # launch of the visit (`skip`: the workgroups of a masked problem return at once, no host sync, no
-            # re-packing) and keep their blocks; a matrix with ONE non-zero block is visited with its sibling.
-            nz = (xv.abs().amax(dim=(2, 3)) > 0)                       # [b, nblk]: block holds a non-zero column
-            lone = (nz.sum(dim=1) == 1).unsqueeze(1)                    # [b, 1]
-        for _ in range(_wide_sweeps(nblk)):
-            for perm, siblings in perms:
-                xp = cur[:, perm].reshape(b * npair, 2 * WIDE_BLOCK, n_pad)
-                skip = None
-                if zero_blocks:
-                    nz = nz[:, perm]
-                    nzp = nz.view(b, npair, 2)
-                    work = nzp.all(dim=2) | (lone & nzp.any(dim=2) & siblings.unsqueeze(0))      # [b, npair]
-                    skip = (~work).reshape(-1).to(torch.int32)
-                rot = _pair_rotation(ops.bgemm_f64(xp, xp, trans_b=True, symmetric=True, skip=skip), skip=skip)
-                new = ops.bgemm_f64(rot, xp, out_dtype=torch.float32, skip=skip)
-                if zero_blocks:
-                    new = torch.where(work.reshape(-1, 1, 1), new, xp)
-                cur = new.view(b, nblk, WIDE_BLOCK, n_pad)
-        xv.copy_(cur[:, restore])
+        xv.copy_(_gram_tournament(ops, xv, zero_blocks, small))
+    if small is not None:
+        x[:, :corner, :corner] = torch.where(small.view(-1, 1, 1), xs_new, x[:, :corner, :corner])
     # the sweep counts are fixed (no host sync): verify on the device that the columns ARE orthogonal and raise the
     # NONCONVERGED bit of the health word otherwise (surfaces as BasdLinAlgError at the next status check)
     gram = ops.bgemm_f64(x, x, trans_b=True, symmetric=True)             # [b, n_pad, n_pad] = column Gram of X
