@@ -333,6 +333,38 @@ def test_blocked_eigensolver_flags_missing_convergence(nat, monkeypatch):
     nat.check_status()
 
 
+@pytest.mark.parametrize("n,ranks", [(768, (120, 350, 384, 385, 500, 768)), (384, (60, 160, 192, 193, 300, 384))])
+def test_blocked_eigensolver_rank_masked_matrices_take_the_right_path(nat, n, ranks):
+    """zero_blocks=True: A is non-zero in its leading k x k corner only (the principal-angle Gram matrices of the wide
+    students).  Matrices whose factor fits the small corner (384 of 768, 192 of 384) take the small path, the others the
+    general tournament, selected per matrix ON THE DEVICE through the kernels' problem masks: one batch with ranks on
+    both sides of the boundary, eigenvalues / vectors of every matrix against eigh, and against the unmasked solver"""
+    from basd_amd.losses import functional as BF, _ops
+    _ops.set_ops(None)
+    g = torch.Generator().manual_seed(n)
+    a = torch.zeros(len(ranks), n, n, dtype=torch.float64)
+    for i, k in enumerate(ranks):
+        c = torch.linalg.qr(torch.randn(k, k, generator=g, dtype=torch.float64))[0]
+        cos = torch.cos(torch.rand(k, generator=g, dtype=torch.float64) * 1.5)          # cosines of principal angles
+        a[i, :k, :k] = (c * cos ** 2) @ c.t()
+    a = a.cuda()
+    s, u, _ = BF.psd_eig(a, zero_blocks=True)
+    nat.check_status()
+    s0, u0, _ = BF.psd_eig(a)                                                            # every matrix through the general path
+    nat.check_status()
+    ref = torch.linalg.eigvalsh(a).flip(-1).clamp_min(0).sqrt()
+    for i, k in enumerate(ranks):
+        top = float(ref[i, 0])
+        assert torch.allclose(s[i, :k].double(), ref[i, :k], rtol=0, atol=1e-5 * top), (k, float((s[i, :k].double() - ref[i, :k]).abs().max()))
+        assert float(s[i, k:].abs().max()) <= 1e-6 * top if k < n else True
+        assert torch.allclose(s[i], s0[i], rtol=0, atol=1e-5 * top)
+        ud = u[i, :k].double()
+        assert float((ud @ ud.t() - torch.eye(k, dtype=torch.float64, device="cuda")).abs().max()) < 1e-5
+        res = ud @ a[i] - (s[i, :k].double() ** 2).unsqueeze(-1) * ud
+        assert float(res.norm(dim=-1).max()) < 3e-5 * top ** 2
+        assert float(u[i, :, k:].abs().max()) == 0.0 if k < n else True                  # eigenvectors stay in the corner
+
+
 def test_blocked_eigensolver_rank_deficient(nat):
     """rank 150 in 384 dimensions: the blocked Cholesky stops at the rank, null directions come back as zero rows"""
     from basd_amd.losses import functional as BF, _ops
