@@ -132,7 +132,8 @@ int basd_pchol_f64_masked(const double* a, int batch, int n, double tol, const d
 
 /* Inverse of the pivoted Cholesky factor left by basd_pchol_f64, fp64, packed triangle in LDS:
  * out[b] = L_p^-1 P  ([n, n] row-major; P = pivot permutation, L_p = P L lower triangular), so
- * out @ M == L_p^-1 (P M) for M with rows in ORIGINAL order.  Rows >= rank[b] are zero. */
+ * out @ M == L_p^-1 (P M) for M with rows in ORIGINAL order.  Rows >= rank[b] are zero.  n <= 208 (blocked on the fp64
+ * matrix cores up to 192; 193 .. 208: blocked leading 192 rows + border rows). */
 int basd_trinv_f64(const double* lwork, const int32_t* piv, const int32_t* rank, int batch, int n,
                    double* out, void* stream);
 /* skip[b] != 0: out[b] untouched (see basd_pchol_f64_masked) */

@@ -404,8 +404,11 @@ def test_status_word_flags_nonfinite_nonconverged_and_rank0(nat):
         nat.check_status()
 
 
-@pytest.mark.parametrize("n,rank", [(32, 32), (32, 20), (192, 192), (192, 100)])
+@pytest.mark.parametrize("n,rank", [(32, 32), (32, 20), (192, 192), (192, 100), (196, 196), (196, 195), (196, 193), (196, 120),
+                                    (208, 208), (200, 197)])
 def test_trinv_matches_triangular_solve(nat, n, rank):
+    """n <= 192: blocked kernel; 193 .. 208 (the 196-token matrices of the wide students): blocked leading 192 rows +
+    border rows"""
     g = torch.Generator().manual_seed(n * 7 + rank)
     z = torch.randn(3, 3 * n, rank, dtype=torch.float64, generator=g) @ torch.randn(3, rank, n, dtype=torch.float64, generator=g)
     a = z.transpose(1, 2) @ z

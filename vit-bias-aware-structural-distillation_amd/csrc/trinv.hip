@@ -101,18 +101,20 @@ __device__ __forceinline__ f64x4t blk_mma(const double* __restrict__ X, int a_of
 
 __global__ __launch_bounds__(768) void trinv_blocked_kernel(const double* __restrict__ lw_all,
                                                             const int32_t* __restrict__ piv_all,
-                                                            const int32_t* __restrict__ rank_all, int n,
+                                                            const int32_t* __restrict__ rank_all, int n, int ld,
                                                             double* __restrict__ out_all, const int32_t* __restrict__ skip) {
+  // n = size of the (leading) block that is inverted here, ld = size / row pitch of the whole matrix (ld > n: the
+  // remaining rows are the border, trinv_border_kernel)
   if (skip != nullptr && skip[blockIdx.x] != 0) return;       // masked problem: output left untouched
   extern __shared__ __align__(16) double X[];          // lower block triangle, 16 x 16 row-major blocks
   const int nb = (n + 15) >> 4;
   double* s_rd = X + (size_t)nb * (nb + 1) / 2 * 256;  // [16 nb] reciprocal diagonal
   int* s_piv = reinterpret_cast<int*>(s_rd + 16 * nb); // [16 nb]
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  const double* Lw = lw_all + (size_t)blockIdx.x * n * n;
-  const int32_t* piv = piv_all + (size_t)blockIdx.x * n;
-  const int rank = rank_all[blockIdx.x];
-  double* out = out_all + (size_t)blockIdx.x * n * n;
+  const double* Lw = lw_all + (size_t)blockIdx.x * ld * ld;
+  const int32_t* piv = piv_all + (size_t)blockIdx.x * ld;
+  const int rank = rank_all[blockIdx.x] < n ? rank_all[blockIdx.x] : n;
+  double* out = out_all + (size_t)blockIdx.x * ld * ld;
 
   for (int i = tid; i < 16 * nb; i += nt) s_piv[i] = (i < n) ? piv[i] : 0;
   __syncthreads();
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(768) void trinv_blocked_kernel(const double* __rest
     const int bj = b - bi * (bi + 1) / 2;
     const int i = 16 * bi + r, k = 16 * bj + c;
     double v = (i == k) ? 1.0 : 0.0;
-    if (k < rank && i < n && k <= i) v = Lw[(size_t)k * n + s_piv[i]];
+    if (k < rank && i < n && k <= i) v = Lw[(size_t)k * ld + s_piv[i]];
     X[b * 256 + r * 16 + c] = v;
   }
   __syncthreads();
@@ -191,7 +193,65 @@ __global__ __launch_bounds__(768) void trinv_blocked_kernel(const double* __rest
     const int k = e / n, c = e - k * n;
     double v = 0.0;
     if (c <= k && k < rank) v = X[blk_off(k >> 4, c >> 4) + (k & 15) * 16 + (c & 15)];
-    out[(size_t)k * n + s_piv[c]] = v;
+    out[(size_t)k * ld + s_piv[c]] = v;
+  }
+  // the columns of the border pivots are zero in the rows of the leading block (the inverse is lower triangular)
+  for (int e = tid; e < n * (ld - n); e += nt) {
+    const int k = e / (ld - n), c = n + e - k * (ld - n);
+    out[(size_t)k * ld + piv[c]] = 0.0;
+  }
+}
+
+// Border rows of L_p^-1 P for n_lead < ld <= n_lead + 16 (the 196-token matrices of the wide students: 192 + 4):
+// with L_p = [[L11, 0], [L21, L22]],  rows i >= n_lead of the inverse are  (e_i^T - L_p[i, :i] X[:i, :]) / L_p[i, i],
+// computed column by column of the OUTPUT layout (out[k, piv[c]] = X[k, c]: the leading rows written by
+// trinv_blocked_kernel are read back row-contiguously, one thread per output column).  The unblocked kernel above
+// needs 0.84 ms per 512 matrices of 196 x 196; blocked leading part + this border: see DESIGN.md section 5.
+__global__ __launch_bounds__(256) void trinv_border_kernel(const double* __restrict__ lw_all,
+                                                           const int32_t* __restrict__ piv_all,
+                                                           const int32_t* __restrict__ rank_all, int n_lead, int ld,
+                                                           double* __restrict__ out_all, const int32_t* __restrict__ skip) {
+  if (skip != nullptr && skip[blockIdx.x] != 0) return;
+  __shared__ double s_l[16][224];                       // s_l[r][k] = L_p[n_lead + r, k], k <= n_lead + r
+  __shared__ int s_pr[16];
+  const int tid = threadIdx.x, nbord = ld - n_lead;
+  const double* Lw = lw_all + (size_t)blockIdx.x * ld * ld;
+  const int32_t* piv = piv_all + (size_t)blockIdx.x * ld;
+  const int rank = rank_all[blockIdx.x];
+  double* out = out_all + (size_t)blockIdx.x * ld * ld;
+  if (tid < nbord) s_pr[tid] = piv[n_lead + tid];
+  __syncthreads();
+  for (int e = tid; e < nbord * ld; e += 256) {
+    const int r = e / ld, k = e - r * ld;
+    s_l[r][k] = (k <= n_lead + r) ? Lw[(size_t)k * ld + s_pr[r]] : 0.0;
+  }
+  __syncthreads();
+  const int j = tid;                                     // output column
+  if (j >= ld) return;
+  double acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = (r < nbord && s_pr[r] == j) ? 1.0 : 0.0;
+  for (int k = 0; k < n_lead; ++k) {
+    const double x = out[(size_t)k * ld + j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r < nbord) acc[r] = fma(-s_l[r][k], x, acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < nbord) {
+      const int i = n_lead + r;
+      double v = 0.0;
+      if (i < rank) {
+        v = acc[r];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (q < r) v = fma(-s_l[r][n_lead + q], acc[q], v);
+        v /= s_l[r][i];
+      }
+      acc[r] = v;                                        // from here on acc[r] = the finished row's entry of column j
+      out[(size_t)i * ld + j] = v;
+    }
   }
 }
 
@@ -207,15 +267,24 @@ extern "C" int basd_trinv_f64_masked(const double* lwork, const int32_t* piv, co
   using namespace basd;
   if (batch <= 0) return BASD_OK;
   const size_t lds = (size_t)n * (n + 1) / 2 * 8 + (size_t)n * 4 + 64;
-  if (n < 1 || lds > 160 * 1024)
-    return fail(BASD_ERR_SHAPE, "trinv_f64: n=%d does not fit the LDS-resident packed triangle", n);
+  if (n < 1 || (lds > 160 * 1024 && n > 208))
+    return fail(BASD_ERR_SHAPE, "trinv_f64: n=%d does not fit the LDS-resident forms (n <= 208)", n);
   const int nb = (n + 15) / 16;
   const size_t lds_blk = (size_t)nb * (nb + 1) / 2 * 256 * 8 + (size_t)16 * nb * (8 + 4);
   if (nb <= 12 && lds_blk <= 160 * 1024) {
     allow_full_lds((const void*)trinv_blocked_kernel);
     hipLaunchKernelGGL(trinv_blocked_kernel, dim3(batch), dim3(768), lds_blk, (hipStream_t)stream, lwork, piv, rank, n,
-                       out, skip);
+                       n, out, skip);
     return check_launch("trinv_f64 (blocked)");
+  }
+  if (n > 192 && n <= 208) {     // 192 leading rows on the blocked kernel, up to 16 border rows behind it
+    const size_t lds12 = (size_t)12 * 13 / 2 * 256 * 8 + (size_t)16 * 12 * (8 + 4);
+    allow_full_lds((const void*)trinv_blocked_kernel);
+    hipLaunchKernelGGL(trinv_blocked_kernel, dim3(batch), dim3(768), lds12, (hipStream_t)stream, lwork, piv, rank, 192,
+                       n, out, skip);
+    hipLaunchKernelGGL(trinv_border_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, lwork, piv, rank, 192, n, out,
+                       skip);
+    return check_launch("trinv_f64 (blocked + border)");
   }
   // 4 lanes per row, rows strided by 192 per pass: two passes cover n <= 384 (v[2])
   allow_full_lds((const void*)trinv_kernel);
