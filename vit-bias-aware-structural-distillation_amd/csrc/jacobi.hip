@@ -521,7 +521,7 @@ __attribute__((amdgpu_waves_per_eu((NMAT == 2 || MAXCH > 7) ? 3 : 4, (NMAT == 2 
 // a quarter of the columns: 384 threads at n = 192, 96 column VGPRs), single mailbox (74 KB): two
 // independent workgroups per CU, so one's hand-over overlaps the other's rotations.
 template <int MAXCH>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void jacobi_blk_kernel(
+__global__ __launch_bounds__(MAXCH > 6 ? 448 : 384) __attribute__((amdgpu_waves_per_eu(MAXCH > 6 ? 2 : 3, MAXCH > 6 ? 2 : 3))) void jacobi_blk_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
     float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status,
     const int32_t* __restrict__ skip) {
@@ -813,7 +813,11 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   // active_rows == 2: `active` is a MASK -- entries are either < 0 (skip the matrix) or n_cols (solve it completely)
   const bool mask_only = active != nullptr && active_rows == 2;
   if (mask_only) active_rows = 0;
-  if ((active == nullptr || mask_only) && batch >= 32 && n_cols <= 192 && oe_ch <= 6 && n_cols >= 8) {
+  // MAXCH = 7 (193 .. 224 rows, up to 196 columns: the 196-token Procrustes cores of the wide students): 112 column
+  // VGPRs (202 in all, no spills), seven waves, one workgroup per CU: 4.02 vs 5.00 ms per 512 matrices of 196 x 196
+  // with the single-mailbox odd-even kernel
+  const bool blk7 = oe_ch == 7 && n_cols <= 196;
+  if ((active == nullptr || mask_only) && batch >= 32 && ((n_cols <= 192 && oe_ch <= 6) || blk7) && n_cols >= 8) {
     // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
     const int nbk = (n_cols + 1) / 2, slots = (nbk + 1) / 2;
     const int threads_b = ((slots * 8 + 63) / 64) * 64;
@@ -826,7 +830,8 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   } while (0)
     if (oe_ch == 2) BASD_LAUNCH_BLK(2);
     else if (oe_ch == 4) BASD_LAUNCH_BLK(4);
-    else BASD_LAUNCH_BLK(6);
+    else if (oe_ch == 6) BASD_LAUNCH_BLK(6);
+    else BASD_LAUNCH_BLK(7);
 #undef BASD_LAUNCH_BLK
     return check_launch("jacobi_svd (block odd-even)");
   }
