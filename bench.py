@@ -49,6 +49,24 @@ CONFIGS = {
 }
 
 
+def _nbytes(t):
+    return t.numel() * t.element_size()
+
+
+# ALGORITHMIC bytes of one launch of the streaming kernels (every captured teacher token read once, every
+# tapped student token once, the E mixed outputs written once), from the arguments / results of the call:
+#   mix_tokens      reads the L teacher layers once, writes the E mixed [B, N, D_t] fp32 tensors
+#   mix_grad_dots   reads the L teacher layers once and the E gradient tensors once (the [E, L] dots are negligible)
+#   procrustes_prep reads the student tokens, the mixed teacher tokens and the importance once, writes s_w and t_w
+#   add_layernorm_fwd (the frozen teacher's fused residual add + LayerNorm) reads x and the residual, writes s and y
+STREAMING = {
+    "mix_tokens": lambda a, k, out: sum(_nbytes(t) for t in a[0]) + _nbytes(out),
+    "mix_grad_dots": lambda a, k, out: sum(_nbytes(t) for t in a[0]) + _nbytes(a[1]),
+    "procrustes_prep": lambda a, k, out: _nbytes(a[0]) + a[1].numel() * 4 + _nbytes(a[2]) + _nbytes(out[0]) + _nbytes(out[1]),
+    "add_layernorm_fwd": lambda a, k, out: 2 * _nbytes(a[0]) + _nbytes(out[0]) + _nbytes(out[1]),
+}
+
+
 class KernelTimer:
     """Device-event timing of the C-ABI kernels, on the stream they are launched on."""
 
@@ -75,6 +93,9 @@ class KernelTimer:
                 if _name in ("gemm_bf16", "gemm_gelu_fwd", "gemm_gelu_bwd"):
                     # (rows, N, K) of y = x w^T: a[0] [..., K], a[1] [N, K]
                     self.meta[_name].append((a[0].numel() // a[0].shape[-1], a[1].shape[0], a[1].shape[1], s, e))
+                if _name in STREAMING:
+                    label = f"{_name}[D={a[0].shape[-1]}]" if _name == "add_layernorm_fwd" else _name
+                    self.meta[_name].append((STREAMING[_name](a, k, out), s, e, label))
                 if _name == "jacobi_svd":
                     # (batch, n_cols, m_rows, rank-masked?) -- masked launches sweep a smaller block
                     self.meta[_name].append((a[0].shape[0], a[0].shape[1], a[1], k.get("active") is not None, s, e, out[1]))
@@ -101,8 +122,72 @@ class KernelTimer:
         return out
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N fresh child processes of this script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would: the reference gets its ranks from
+    ``accelerate launch``, src/training/trainer.py:80-82), relay rank 0's stdout (the JSON line) and return non-zero if
+    any rank failed.  The parent never touches the GPU (no torch.cuda call before this point), so nothing that holds a
+    device context is ever re-executed."""
+    import subprocess
+    import tempfile
+    port = _free_port()
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BASD_BENCH_LAUNCHER="self")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        rc = 0
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:                                  # a rank died: the others would wait in a collective for ever --
+                rc = bad[0] if bad[0] > 0 else 1     # stop exactly the children started here
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.kill()
+                for pr in procs:
+                    pr.wait()
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.2)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
+    return rc
+
+
+def launch_check() -> None:
+    """--launch-check: what a rank does when only the rendezvous is under test (CPU, gloo): initialise the process
+    group the launcher's environment describes, all-reduce one value, rank 0 prints a JSON line with the world size
+    torch.distributed actually sees (tests/test_bench_launcher_cpu.py)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    seen, total = 1, 1.0
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen, total = dist.get_world_size(), float(t)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": seen, "backend": "gloo",
+                          "all_reduce_of_ones": total, "launcher": os.environ.get("BASD_BENCH_LAUNCHER", "external")}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous rehearsal on CPU (gloo): no GPU work")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -110,7 +195,7 @@ def main():
                     "the one the metric is quoted on)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU baseline sample (default: the metric's 256 images: one timed CPU step, ~30 s on 16 cores)")
+    ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU baseline sample (default: the metric's 256 images: one warm-up + one timed CPU step, ~40 s each on 16 cores)")
     ap.add_argument("--global-batch", type=int, default=None, help="STRONG scaling: fix the global batch (e.g. 256) and give every rank global / world images; default: weak scaling, --batch images per GPU")
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="further config overrides (A/B "
@@ -120,6 +205,13 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the teacher forward of batch k + 1 with "
                     "loss / backward of batch k (every step then starts with its own teacher forward)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (before any torch.cuda call)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks")
+    if args.launch_check:
+        return launch_check()
     student_preset, teacher_preset, img_size, patch, cfg_batch, F_STUDENT, F_TEACHER, workload = CONFIGS[args.config]
     if args.batch is None:
         args.batch = cfg_batch
@@ -178,7 +270,7 @@ def main():
 
     timer = KernelTimer(native, ["jacobi_svd", "pchol", "trinv", "bgemm_f64", "token_gram", "mix_tokens",
                                  "mix_grad_dots", "procrustes_prep", "wgrad_bf16", "sf_adamw_step", "mp_rank",
-                                 "gemm_bf16", "gemm_gelu_fwd", "gemm_gelu_bwd"])
+                                 "gemm_bf16", "gemm_gelu_fwd", "gemm_gelu_bwd", "add_layernorm_fwd"])
     timer.install()
 
     # a few eager steps first: rank sanity check + (events cannot be recorded inside a captured graph)
@@ -192,6 +284,10 @@ def main():
         progress(f"eager step {i}: loss {float(loss):.4f}")
         if i == 0:
             timer.active = False
+            # the instrumented steps run on ONE stream (the product schedule puts the teacher branch on a side stream:
+            # every kernel then shares the GPU and a device-event bracket measures the sharing, not the kernel)
+            stream_flags = (trainer.overlap_teacher_stats, trainer.overlap_teacher_forward)
+            trainer.overlap_teacher_stats = trainer.overlap_teacher_forward = False
             ranks = trainer.basd_loss.layer_selector.subspace_ranks
             if min(ranks.values()) < 1 or not torch.isfinite(loss):
                 raise SystemExit(f"synthetic batch gives a rank-0 teacher layer / non-finite loss: {ranks} {loss}")
@@ -201,6 +297,7 @@ def main():
             timer.active = True
     torch.cuda.synchronize()
     timer.active = False
+    trainer.overlap_teacher_stats, trainer.overlap_teacher_forward = stream_flags       # product schedule from here on
     timer.launch_procrustes_entry_by_entry(False)      # the captured / timed steps use the composite entry
     probe_steps = eager_probe - 1
     graphed = False
@@ -340,16 +437,36 @@ def main():
                     "launches_per_step": g_n / probe_steps, "ms_per_step": g_ms / probe_steps,
                     "largest_shapes": {k_: {"launches_per_step": v_[0] / probe_steps, "avg_us": 1e3 * v_[1] / v_[0],
                                             "tflops": v_[2] * v_[0] / (v_[1] / 1e3) / 1e12} for k_, v_ in top},
-                    "measured_in": "device events around every GEMM entry in the instrumented eager probe steps "
-                                   "(single stream: the GEMMs have the GPU to themselves there)"}
+                    "measured_in": "device events around every GEMM entry in the instrumented eager probe steps; those "
+                                   "steps run teacher and student on ONE stream (overlap switched off for them), so each "
+                                   "GEMM has the GPU to itself; eager launches still carry a few us of launch latency each"}
+        # ---- streaming stages (>= 60 % of the 8 TB/s HBM peak is the target): algorithmic bytes of the
+        # launch / device-event time, single stream
+        streaming = {}
+        by_label = {}
+        for name in STREAMING:
+            for r in timer.meta.get(name, []):
+                by_label.setdefault(r[3], []).append(r)
+        for name, recs in by_label.items():
+            if recs:
+                by, ms = sum(r[0] for r in recs), sum(r[1].elapsed_time(r[2]) for r in recs)
+                streaming[name] = {"launches_per_step": len(recs) / probe_steps, "algorithmic_bytes_per_launch": by / len(recs),
+                                   "avg_us": 1e3 * ms / len(recs), "achieved": by / (ms / 1e3) / 1e9, "peak": 8000.0,
+                                   "unit": "GB/s", "frac": by / (ms / 1e3) / 1e9 / 8000.0}
+        if streaming:
+            tot_b = sum(v["algorithmic_bytes_per_launch"] * v["launches_per_step"] for v in streaming.values())
+            tot_s = sum(v["avg_us"] * v["launches_per_step"] for v in streaming.values()) / 1e6
+            streaming["all"] = {"bound": "hbm", "achieved": tot_b / tot_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                "frac": tot_b / tot_s / 1e9 / 8000.0, "bytes_per_step": tot_b,
+                                "measured_in": "device events in the single-stream instrumented probe steps"}
         vit_flops = global_batch * ((4 if args.grad_checkpointing else 3) * F_STUDENT + F_TEACHER)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_step import cpu_step_images_per_sec
             print("[bench] GPU timing done; timing the CPU baseline sample", file=sys.stderr, flush=True)
-            # the metric's own batch (256): one timed step, no warm-up step (~30 s of CPU work on the 16-core share)
+            # the metric's own batch (256): one warm-up step + one timed step (~2 x 40 s of CPU work on the 16-core share)
             small = args.cpu_batch < 128
-            cpu = cpu_step_images_per_sec(batch=args.cpu_batch, timed_steps=3 if small else 1, warmup=1 if small else 0)
+            cpu = cpu_step_images_per_sec(batch=args.cpu_batch, timed_steps=3 if small else 1, warmup=1)
         line = {
             "metric": ("images/sec BASD train step, DeiT-T student / ViT-B teacher bs=256" if args.config == "c2" else
                        f"images/sec BASD train step, {student_preset} student / {teacher_preset} teacher"),
@@ -362,6 +479,9 @@ def main():
                        "grad_checkpointing": bool(args.grad_checkpointing)},
             "roofline": roof,
             "roofline_top_by_total_time": gemm,
+            "roofline_streaming": streaming,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "launcher": os.environ.get("BASD_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "none"),
             "cpu_baseline": cpu,
             "library_fallbacks": dict(__import__("basd_amd.losses._ops", fromlist=["FALLBACKS"]).FALLBACKS),
             "vit_gemm": {"algorithmic_tflop_per_step": vit_flops / 1e12,

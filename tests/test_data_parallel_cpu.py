@@ -119,6 +119,7 @@ def _trainer_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     trainer = _c1_trainer()
     assert trainer.reducer.enabled and trainer.reducer.world == 2 and len(trainer.reducer.buckets) >= 5
+    assert not trainer.segmented          # the two-stage captured backward is opt-in (basd.segmented_backward)
     batch = _shard(rank)
     out = {}
     # path 1: bucket hooks fire during backward, finish() waits and averages

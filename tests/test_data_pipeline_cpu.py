@@ -89,6 +89,54 @@ def test_augmentation_rng_is_reproducible_and_per_sample(tmp_path):
     assert not torch.equal(a[0], a[1])
 
 
+def test_epochs_draw_fresh_augmentations_through_persistent_workers(tmp_path):
+    """the epoch must reach the worker processes (persistent workers keep their pickled copy of the dataset):
+    two consecutive epochs give different 'augmented' views and identical 'clean' views for the same image; the same
+    epoch number replays the same views"""
+    from basd_amd.data import create_dataloaders
+    root = _make_root(tmp_path)
+    cfg = _cfg(root)
+    stats = ((0.5, 0.5, 0.5), (0.25, 0.25, 0.25))
+    for workers in (0, 2):
+        train, _ = create_dataloaders(cfg, teacher_stats=stats, num_workers=workers)
+        assert train.dataset.transform.epoch == 0
+
+        def epoch_views(e):
+            train.dataset.set_epoch(e)
+            views = {}
+            for b in train:
+                for c, a in zip(b["clean"], b["augmented"]):
+                    views[c.numpy().tobytes()] = a.clone()      # the clean view identifies the image
+            return views
+
+        e0, e1, e0_again = epoch_views(0), epoch_views(1), epoch_views(0)
+        assert set(e0) == set(e1) == set(e0_again) and len(e0) == 24      # same clean views (no two images coincide)
+        assert sum(int(not torch.equal(e0[k], e1[k])) for k in e0) >= 20  # fresh crops / flips / ops in the next epoch
+        assert all(torch.equal(e0[k], e0_again[k]) for k in e0)           # (seed, epoch, index) is reproducible
+        del train
+
+
+def test_trainer_advances_the_loader_epoch():
+    """Trainer.train tells the dataset which epoch it is in (datasets with a set_epoch hook)"""
+    import types
+    from basd_amd.training.trainer import Trainer
+    seen = []
+
+    class _DS:
+        def set_epoch(self, e):
+            seen.append(e)
+
+    loader = types.SimpleNamespace(dataset=_DS())
+    fake = types.SimpleNamespace(
+        config=types.SimpleNamespace(training=types.SimpleNamespace(num_epochs=3)),
+        optimizer=types.SimpleNamespace(train=lambda: None, eval=lambda: None), model=types.SimpleNamespace(train=lambda: None),
+        _train_epoch=lambda l: {"train_loss": 0.0}, metrics_history={"train_loss": []}, best_val_acc=0.0,
+        save_checkpoint=lambda *a: None, save_weights=lambda *a: None)
+    fake.metrics_history = __import__("collections").defaultdict(list)
+    Trainer.train(fake, loader, None, start_epoch=1)
+    assert seen == [1, 2]
+
+
 def test_transform_pieces_follow_the_torchvision_definitions():
     from basd_amd.data import transforms as T
     g = torch.Generator().manual_seed(3)

@@ -466,11 +466,13 @@ def test_an_in_place_refilled_batch_buffer_is_not_mistaken_for_the_same_batch():
 
 
 @pytest.mark.parametrize("pipe", [False, True])
-def test_two_stage_captured_backward_equals_the_single_graph(pipe):
-    """what a multi-rank run captures (graph A: forward, loss, backward down to the second extraction point; the late
+def test_two_stage_captured_backward_equals_the_single_graph(pipe, monkeypatch):
+    """the opt-in two-stage capture (graph A: forward, loss, backward down to the second extraction point; the late
     gradient slice is all-reduced while graph B finishes the backward) against the one-graph step, forced on one rank:
-    same losses and weights; eager two-stage step 0 equals the plain eager step"""
+    same losses and weights; eager two-stage step 0 equals the plain eager step.  BASD_CHECK_SEGMENTS=1 also checks the
+    invariant the overlap rests on at every replay: stage 2 leaves the late slice of the flat gradient buffer alone"""
     from basd_amd.train import SyntheticLoader
+    monkeypatch.setenv("BASD_CHECK_SEGMENTS", "1")
     batches = [next(iter(SyntheticLoader(32, 32, 100, 1, "cuda", seed=90 + i))) for i in range(2)]
     runs = {}
     for seg in (False, True):

@@ -5,6 +5,7 @@ module raises.  torch is used only for device memory and streams.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -679,6 +680,19 @@ def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor, skip: torc
 # the Trainer sets 2 while its two-stream pipelined step is in use (a persistent launch holds every CU until it ends and
 # the other stream's short kernels queue behind it: measured 41.3 vs 39.5 ms per c2 step).
 GEMM_TILE_RUN = 0
+
+
+@contextlib.contextmanager
+def gemm_tile_run(k: int):
+    """``with gemm_tile_run(2):`` -- the GEMM entries called inside retire their workgroups every k tiles (0: fully
+    persistent, the fastest form when the launch has the GPU to itself).  Scoped: the Trainer wraps only the steps that
+    really run two streams; evaluation, inference and any other model in the process keep the default."""
+    global GEMM_TILE_RUN
+    prev, GEMM_TILE_RUN = GEMM_TILE_RUN, int(k)
+    try:
+        yield
+    finally:
+        GEMM_TILE_RUN = prev
 
 
 def gemm_supported(n: int, k: int) -> bool:

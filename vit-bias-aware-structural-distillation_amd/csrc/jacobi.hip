@@ -771,6 +771,426 @@ __global__ __launch_bounds__(MAXCH > 6 ? 448 : 384) __attribute__((amdgpu_waves_
   report_status(status, converged, s_sig, n_tot, tid, blockDim.x, 5, mat);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Quad-block ordering with scaled rotations (round 4; the default for batches of up to 192 x 192).
+// What the block kernel above still pays per rotation and wave: the rotation parameters (five
+// transcendentals, ~25 VALU instructions) are computed by all 8 lanes of a slot, i.e. 8 distinct
+// parameter sets per wave instruction stream; the plane rotation is four FMAs per row pair; and the
+// mailbox costs two barriers per hand-over.  Here
+//   * a slot is 16 lanes (12 rows per lane at 192 rows) and owns two blocks of FOUR columns (the same 96
+//     column VGPRs); a meeting of two blocks is 16 cross rotations in four rounds of four INDEPENDENT
+//     rotations, one hand-over per 16 rotations (block kernel: per 4);
+//   * the four dot products of a round are reduced with a reduce-scatter (11 DPP / select instructions for
+//     all four), after which lane q of every quad holds rotation q's sum and computes rotation q's
+//     parameters: ONE parameter instruction stream serves four rotations per slot, 16 per wave;
+//   * the per-column bookkeeping (squared norm, scale, id) is DISTRIBUTED: lane q of a quad owns column q of
+//     either block; a round fetches / returns the partner column's entry with one quad_perm each;
+//   * rotations are applied as two shears on scaled columns (x = dx x~, y = dy y~):
+//         x~' = x~ - a y~,  y~' = y~ + b x~',   a = t dy / dx,  b = s c dx / dy,  dx' = c dx,  dy' = dy / c
+//     -- exactly the rotation x' = c x - s y, y' = s x + c y, two FMAs per row pair instead of four, in place.
+//     The scales follow dx' = dx - dx h, dy' = dy + dy h / c with h = 1 - c = s^2 / (1 + c) computed without
+//     cancellation: a c that rounds to 1 (t^2 < eps) must not inflate the norms (the bias the Rutishauser form
+//     removed from the unscaled kernels); the scales are folded back into the columns once per sweep, where the
+//     exact norms are recomputed anyway, so a scale is the product of at most ~190 factors in [0.70, 1.42].
+//   * ONE barrier per hand-over: box j is written by slot j (even steps) or slot j - 1 (odd steps) and read by
+//     the other one after the barrier; the next write to it comes from the slot that just read it (same lanes,
+//     same addresses, LDS operations of a wave execute in order), so no second barrier is needed.
+template <int CTRL> __device__ __forceinline__ float dppf(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int dppi(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__host__ __device__ constexpr int qperm(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+
+// lane (l & 3) = q of every quad receives sum over the 16 lanes of its row of p_q
+__device__ __forceinline__ float reduce_scatter4x16(float p0, float p1, float p2, float p3, bool bit0, bool bit1) {
+  const float keepA = bit0 ? p1 : p0, giveA = bit0 ? p0 : p1;
+  const float keepB = bit0 ? p3 : p2, giveB = bit0 ? p2 : p3;
+  const float uA = keepA + dppf<qperm(1, 0, 3, 2)>(giveA);
+  const float uB = keepB + dppf<qperm(1, 0, 3, 2)>(giveB);
+  const float keep = bit1 ? uB : uA, give = bit1 ? uA : uB;
+  float v = keep + dppf<qperm(2, 3, 0, 1)>(give);
+  // across the four quads: row_ror:8 FIRST, then row_ror:4.  In this order every step adds the same two operands in
+  // all lanes that end up with the same sum (l and l + 8, then l and l + 4), so the four quads hold BITWISE identical
+  // copies.  (ror:4 then ror:8 pairs the partial sums differently in quads {0, 2} and {1, 3}: replicas that differ in
+  // the last bit -- and inside a cluster of equal singular values the sign of beta - alpha, i.e. the direction of a
+  // 45-degree rotation, then differs between the rows of one column.)
+  v += dppf<0x128>(v);                              // row_ror:8
+  v += dppf<0x124>(v);                              // row_ror:4
+  return v;
+}
+
+// the two shears of a scaled rotation on four rows, in place: ab = {a, b}
+__device__ __forceinline__ void shear_in_place(v4f& xa, v4f& ya, v2f_rot ab) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    v2f_rot x = h ? (v2f_rot){xa.z, xa.w} : (v2f_rot){xa.x, xa.y};
+    v2f_rot y = h ? (v2f_rot){ya.z, ya.w} : (v2f_rot){ya.x, ya.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(x) : "v"(ab), "v"(y));   // x - a y
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(y) : "v"(ab), "v"(x));                // y + b x'
+    if (h) { xa.z = x.x; xa.w = x.y; ya.z = y.x; ya.w = y.y; }
+    else { xa.x = x.x; xa.y = x.y; ya.x = y.x; ya.y = y.y; }
+  }
+}
+
+// partial dot products (over this lane's rows) of the four column pairs of a round, on the packed FMA, the four
+// accumulation chains interleaved.  Written as asm: left to itself the SLP vectoriser packs the four dot products
+// ACROSS columns and pays four v_mov per v_pk_fma.
+#define BASD_LO2(v) __builtin_shufflevector(v, v, 0, 1)
+#define BASD_HI2(v) __builtin_shufflevector(v, v, 2, 3)
+template <int MAXCH>
+__device__ __forceinline__ void dot4_cols(const v4f (&A0)[MAXCH], const v4f (&B0)[MAXCH], const v4f (&A1)[MAXCH],
+                                          const v4f (&B1)[MAXCH], const v4f (&A2)[MAXCH], const v4f (&B2)[MAXCH],
+                                          const v4f (&A3)[MAXCH], const v4f (&B3)[MAXCH], float (&p)[4]) {
+  v2f_rot a0, a1, a2, a3;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(a0) : "v"(BASD_LO2(A0[0])), "v"(BASD_LO2(B0[0])));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(a1) : "v"(BASD_LO2(A1[0])), "v"(BASD_LO2(B1[0])));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(a2) : "v"(BASD_LO2(A2[0])), "v"(BASD_LO2(B2[0])));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(a3) : "v"(BASD_LO2(A3[0])), "v"(BASD_LO2(B3[0])));
+  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(BASD_HI2(A0[0])), "v"(BASD_HI2(B0[0])));
+  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(BASD_HI2(A1[0])), "v"(BASD_HI2(B1[0])));
+  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(BASD_HI2(A2[0])), "v"(BASD_HI2(B2[0])));
+  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a3) : "v"(BASD_HI2(A3[0])), "v"(BASD_HI2(B3[0])));
+#pragma unroll
+  for (int ch = 1; ch < MAXCH; ++ch) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(BASD_LO2(A0[ch])), "v"(BASD_LO2(B0[ch])));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(BASD_LO2(A1[ch])), "v"(BASD_LO2(B1[ch])));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(BASD_LO2(A2[ch])), "v"(BASD_LO2(B2[ch])));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a3) : "v"(BASD_LO2(A3[ch])), "v"(BASD_LO2(B3[ch])));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(BASD_HI2(A0[ch])), "v"(BASD_HI2(B0[ch])));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(BASD_HI2(A1[ch])), "v"(BASD_HI2(B1[ch])));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(BASD_HI2(A2[ch])), "v"(BASD_HI2(B2[ch])));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a3) : "v"(BASD_HI2(A3[ch])), "v"(BASD_HI2(B3[ch])));
+  }
+  p[0] = a0.x + a0.y; p[1] = a1.x + a1.y; p[2] = a2.x + a2.y; p[3] = a3.x + a3.y;
+}
+
+// One round = four independent rotations (X_i, Y_i), i = 0..3, column indices 0..7 (0-3 block P, 4-7 block Q)
+// covering all eight columns of the slot.  Lane q of a quad computes rotation q.
+template <int X0, int Y0, int X1, int Y1, int X2, int Y2, int X3, int Y3>
+struct RoundMap {
+  __host__ __device__ static constexpr int X(int i) { return i == 0 ? X0 : (i == 1 ? X1 : (i == 2 ? X2 : X3)); }
+  __host__ __device__ static constexpr int Y(int i) { return i == 0 ? Y0 : (i == 1 ? Y1 : (i == 2 ? Y2 : Y3)); }
+  // gather: lane q takes the entry of column X[q] / Y[q] from its owner lane (column & 3) of register P (column < 4) or Q
+  static constexpr int gx = qperm(X0 & 3, X1 & 3, X2 & 3, X3 & 3), gy = qperm(Y0 & 3, Y1 & 3, Y2 & 3, Y3 & 3);
+  static constexpr int xq_mask = (X0 >> 2) | ((X1 >> 2) << 1) | ((X2 >> 2) << 2) | ((X3 >> 2) << 3);   // bit q: X[q] in block Q
+  static constexpr int yq_mask = (Y0 >> 2) | ((Y1 >> 2) << 1) | ((Y2 >> 2) << 2) | ((Y3 >> 2) << 3);
+  // scatter: owner lane j of P[j] (Q[j]) takes the new entry from the rotation that held the column
+  static constexpr int src_of(int col) {
+    for (int i = 0; i < 4; ++i) if (X(i) == col || Y(i) == col) return i;
+    return 0;
+  }
+  static constexpr bool from_y(int col) {
+    for (int i = 0; i < 4; ++i) if (Y(i) == col) return true;
+    return false;
+  }
+  static constexpr int sp = qperm(src_of(0), src_of(1), src_of(2), src_of(3));
+  static constexpr int sq = qperm(src_of(4), src_of(5), src_of(6), src_of(7));
+  static constexpr int py_mask = (from_y(0) ? 1 : 0) | (from_y(1) ? 2 : 0) | (from_y(2) ? 4 : 0) | (from_y(3) ? 8 : 0);
+  static constexpr int qy_mask = (from_y(4) ? 1 : 0) | (from_y(5) ? 2 : 0) | (from_y(6) ? 4 : 0) | (from_y(7) ? 8 : 0);
+};
+template <int CTRL> __device__ __forceinline__ float qgather(float v) {
+  if constexpr (CTRL == qperm(0, 1, 2, 3)) return v;
+  else return dppf<CTRL>(v);
+}
+template <int GCTRL, int QMASK> __device__ __forceinline__ float meta_gather(float mp, float mq, int q) {
+  if constexpr (QMASK == 0) return qgather<GCTRL>(mp);
+  else if constexpr (QMASK == 15) return qgather<GCTRL>(mq);
+  else {
+    const float a = qgather<GCTRL>(mp), b = qgather<GCTRL>(mq);
+    return ((QMASK >> q) & 1) ? b : a;
+  }
+}
+template <int SCTRL, int YMASK> __device__ __forceinline__ float meta_scatter(float xn, float yn, int q) {
+  if constexpr (YMASK == 0) return qgather<SCTRL>(xn);
+  else if constexpr (YMASK == 15) return qgather<SCTRL>(yn);
+  else {
+    const float a = qgather<SCTRL>(xn), b = qgather<SCTRL>(yn);
+    return ((YMASK >> q) & 1) ? b : a;
+  }
+}
+
+template <int MAXCH>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void jacobi_b4_kernel(
+    float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
+    float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status,
+    const int32_t* __restrict__ skip) {
+  extern __shared__ __align__(16) float lds[];
+  if (skip != nullptr && skip[blockIdx.x] < 0) {   // masked problem: nothing is read or written
+    if (sweeps_out && threadIdx.x == 0) sweeps_out[blockIdx.x] = 0;
+    return;
+  }
+  constexpr int LDC = 64 * MAXCH;                  // one column in the mailbox
+  constexpr int LDB = 4 * LDC;                     // one block
+  const int tid = threadIdx.x;
+  const int k = tid >> 4, sub = tid & 15, roff = sub * 4, q = sub & 3;
+  const bool bit0 = (sub & 1) != 0, bit1 = (sub & 2) != 0;
+  const int nb = (n + 3) >> 2;                     // blocks that hold real columns
+  const int nbe = nb + (nb & 1);                   // line length in blocks (a zero phantom block pads odd nb)
+  const int S = nbe >> 1;                          // slots
+  float* mbox = lds;                               // [S + 1][LDB]
+  float* s_sig = mbox + (size_t)(S + 1) * LDB;     // [8 S] by position
+  int* s_rank = reinterpret_cast<int*>(s_sig + 200);      // [8 S]
+  int* s_pid = s_rank + 200;                       // [8 S] column id by position
+  int* s_id = s_pid + 200;                         // [S + 1][4] ids travelling with the mailbox
+  float* s_nrm = reinterpret_cast<float*>(s_id + 104);    // [S + 1][4] squared norms
+  float* s_scl = s_nrm + 104;                      // [S + 1][4] scales
+  int* s_flag = reinterpret_cast<int*>(s_scl + 104);      // [2] any rotation, [2] any LARGE rotation, [2] max norm
+
+  const int mat = blockIdx.x;
+  float* src = wg + (size_t)mat * n * ld;
+  const int mr = (m + 3) & ~3;
+  const bool live = k < S;
+  const bool last = k == S - 1;
+  float* const mybox = mbox + (size_t)k * LDB + roff;          // box k, this lane's rows
+  int* const mymeta = s_id + 4 * k + q;                         // box k, this lane's column: id, +104 norm, +208 scale
+  float* const mymeta_f = reinterpret_cast<float*>(mymeta);
+  v4f C[8][MAXCH];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int idc = 8 * k + c;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      const int r = roff + 64 * ch;
+      C[c][ch] = (live && idc < n && r < mr) ? *reinterpret_cast<const v4f*>(src + (size_t)idc * ld + r)
+                                             : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // distributed bookkeeping: lane q of every quad owns column q of block P (C[q]) and of block Q (C[4 + q])
+  int idP = 8 * k + q, idQ = 8 * k + 4 + q;
+  float nP = 0.f, nQ = 0.f, dP = 1.f, dQ = 1.f;
+  if (tid < 8) s_flag[tid] = 0;
+  __syncthreads();
+
+  const float inv_tol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / tol)));
+  bool rotated = false, bigrot = false;
+
+  auto round = [&](auto map, bool ok) {
+    using M = decltype(map);
+    float p[4];
+    dot4_cols<MAXCH>(C[M::X(0)], C[M::Y(0)], C[M::X(1)], C[M::Y(1)], C[M::X(2)], C[M::Y(2)], C[M::X(3)], C[M::Y(3)], p);
+    const float gt = reduce_scatter4x16(p[0], p[1], p[2], p[3], bit0, bit1);
+    const float al = meta_gather<M::gx, M::xq_mask>(nP, nQ, q), be = meta_gather<M::gy, M::yq_mask>(nP, nQ, q);
+    const float dx = meta_gather<M::gx, M::xq_mask>(dP, dQ, q), dy = meta_gather<M::gy, M::yq_mask>(dP, dQ, q);
+    const float g = gt * dx * dy;                  // dot product of the true columns
+    const float gsc = g * inv_tol;
+    const bool rot = ok & (gsc * gsc > fmaxf(al * be, BASD_JACOBI_TINY));
+    {
+      // no branch around the rotation: a round in which all 16 rotations of the wave are below the threshold only
+      // occurs on padded / rank-deficient columns (the solve stops after the first sweep of small rotations), and a
+      // merge point after the in-place shears costs 48 register moves per round (the allocator does not coalesce the
+      // halves of the column registers across it); converged pairs run the shears with a = b = 0, an exact no-op
+      rotated |= rot;
+      const float gq = g * (1.0f / BASD_JACOBI_QUAD);
+      const bool big_cos = gq * gq > al * be;
+      const float z = (be - al) * __builtin_amdgcn_rcpf(2.f * g);
+      float t = copysignf(1.f, z) * __builtin_amdgcn_rcpf(fabsf(z) + __builtin_amdgcn_sqrtf(fmaf(z, z, 1.f)));
+      t = rot ? t : 0.f;
+      bigrot |= rot & (big_cos | (fabsf(t) > BASD_JACOBI_QUAD_TAN));
+      const float w = fmaf(t, t, 1.f);
+      float c = __builtin_amdgcn_rsqf(w);
+      c = c * fmaf(-0.5f * w, c * c, 1.5f);
+      const float sn = c * t;
+      const float u = sn * __builtin_amdgcn_rcpf(1.0f + c);
+      const float h = sn * u, hp = t * u;          // 1 - c and 1 / c - 1, no cancellation
+      const float aln = fmaf(-t, g, al), ben = fmaf(t, g, be);
+      const float a = t * (dy * __builtin_amdgcn_rcpf(dx));
+      const float b = (sn * c) * (dx * __builtin_amdgcn_rcpf(dy));
+      const float dxn = fmaf(-dx, h, dx), dyn = fmaf(dy, hp, dy);
+      nP = meta_scatter<M::sp, M::py_mask>(aln, ben, q);
+      nQ = meta_scatter<M::sq, M::qy_mask>(aln, ben, q);
+      dP = meta_scatter<M::sp, M::py_mask>(dxn, dyn, q);
+      dQ = meta_scatter<M::sq, M::qy_mask>(dxn, dyn, q);
+      v2f_rot ab[4];
+      ab[0] = (v2f_rot){dppf<qperm(0, 0, 0, 0)>(a), dppf<qperm(0, 0, 0, 0)>(b)};
+      ab[1] = (v2f_rot){dppf<qperm(1, 1, 1, 1)>(a), dppf<qperm(1, 1, 1, 1)>(b)};
+      ab[2] = (v2f_rot){dppf<qperm(2, 2, 2, 2)>(a), dppf<qperm(2, 2, 2, 2)>(b)};
+      ab[3] = (v2f_rot){dppf<qperm(3, 3, 3, 3)>(a), dppf<qperm(3, 3, 3, 3)>(b)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) shear_in_place(C[M::X(i)][ch], C[M::Y(i)][ch], ab[i]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // fold the scales into the columns (x <- d x~, d <- 1); `kill` zeroes a column instead
+  auto fold = [&](bool killP, bool killQ) {
+    const float fP = killP ? 0.f : dP, fQ = killQ ? 0.f : dQ;
+    float f[8];
+    f[0] = dppf<qperm(0, 0, 0, 0)>(fP); f[1] = dppf<qperm(1, 1, 1, 1)>(fP);
+    f[2] = dppf<qperm(2, 2, 2, 2)>(fP); f[3] = dppf<qperm(3, 3, 3, 3)>(fP);
+    f[4] = dppf<qperm(0, 0, 0, 0)>(fQ); f[5] = dppf<qperm(1, 1, 1, 1)>(fQ);
+    f[6] = dppf<qperm(2, 2, 2, 2)>(fQ); f[7] = dppf<qperm(3, 3, 3, 3)>(fQ);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) C[c][ch] *= f[c];
+    }
+    dP = 1.f; dQ = 1.f;
+  };
+  auto exact_norms = [&](int rows) {
+    float p[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) {
+        const int r = roff + 64 * ch;
+        const v4f x = C[c][ch];
+        const float mx = (r + 0 < rows) ? 1.f : 0.f, my = (r + 1 < rows) ? 1.f : 0.f;
+        const float mz = (r + 2 < rows) ? 1.f : 0.f, mw = (r + 3 < rows) ? 1.f : 0.f;
+        a = fmaf(mx * x.x, x.x, fmaf(my * x.y, x.y, fmaf(mz * x.z, x.z, fmaf(mw * x.w, x.w, a))));
+      }
+      p[c] = a;
+    }
+    nP = reduce_scatter4x16(p[0], p[1], p[2], p[3], bit0, bit1);
+    nQ = reduce_scatter4x16(p[4], p[5], p[6], p[7], bit0, bit1);
+  };
+
+  int used_sweeps = 0;
+  bool converged = false;
+  int step = 0;                                    // even = blocks (2k, 2k+1); nbe is even, sweeps start and end there
+#pragma unroll 1
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    rotated = false;
+    bigrot = false;
+    fold(false, false);
+    exact_norms(1 << 30);
+    if (live && sub < 4) atomicMax(&s_flag[4 + (sweep & 1)], __float_as_int(fmaxf(nP, nQ)));
+    lds_barrier();
+    {
+      const float debris = __int_as_float(s_flag[4 + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
+      const bool zP = nP < debris, zQ = nQ < debris;       // debris columns become exact zero columns
+      if (__builtin_amdgcn_ballot_w64(zP || zQ) != 0) {
+        fold(zP, zQ);
+        if (zP) nP = 0.f;
+        if (zQ) nQ = 0.f;
+      }
+    }
+    // the six pairs inside each block, once per sweep: three rounds of two pairs per block
+    round(RoundMap<0, 1, 2, 3, 4, 5, 6, 7>{}, live);
+    round(RoundMap<0, 2, 1, 3, 4, 6, 5, 7>{}, live);
+    round(RoundMap<0, 3, 1, 2, 4, 7, 5, 6>{}, live);
+#pragma unroll 1
+    for (int t = 0; t < nbe; ++t, ++step) {
+      const bool even_view = (step & 1) == 0;
+      const bool pair_ok = live & (even_view | !last);
+      round(RoundMap<0, 4, 1, 5, 2, 6, 3, 7>{}, pair_ok);
+      round(RoundMap<0, 5, 1, 6, 2, 7, 3, 4>{}, pair_ok);
+      round(RoundMap<0, 6, 1, 7, 2, 4, 3, 5>{}, pair_ok);
+      round(RoundMap<0, 7, 1, 4, 2, 5, 3, 6>{}, pair_ok);
+      // ---- hand one block over (positions swap after a meeting: the pair is then stored as lo = Q, hi = P).
+      // ONE base address per lane for the boxes and one for their bookkeeping entries; everything else is an
+      // immediate offset (box k at 0, box k + 1 at LDB; ids / norms / scales 104 entries apart)
+      if (even_view) {
+        // Q (block position 2k) goes to slot k-1 through box k (slot 0's stays parked there); the last slot has no
+        // right neighbour: it parks its P in box S and takes it back as Q (its lone block of the odd view)
+        if (live) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + c * LDC + 64 * ch) = C[4 + c][ch];
+          }
+          if (sub < 4) { mymeta[0] = idQ; mymeta_f[104] = nQ; mymeta_f[208] = dQ; }
+          if (last) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+              for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + 64 * ch) = C[c][ch];
+            }
+            if (sub < 4) { mymeta[4] = idP; mymeta_f[104 + 4] = nP; mymeta_f[208 + 4] = dP; }
+          }
+        }
+        lds_barrier();
+        if (live) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) C[4 + c][ch] = *reinterpret_cast<const v4f*>(mybox + LDB + c * LDC + 64 * ch);
+          }
+          idQ = mymeta[4]; nQ = mymeta_f[104 + 4]; dQ = mymeta_f[208 + 4];
+        }
+      } else {
+        // P (position 2k+2 after the swap) goes to slot k+1 through box k+1; slot 0 takes the parked block back
+        if (live && !last) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + 64 * ch) = C[c][ch];
+          }
+          if (sub < 4) { mymeta[4] = idP; mymeta_f[104 + 4] = nP; mymeta_f[208 + 4] = dP; }
+        }
+        lds_barrier();
+        if (live) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) C[c][ch] = *reinterpret_cast<const v4f*>(mybox + c * LDC + 64 * ch);
+          }
+          idP = mymeta[0]; nP = mymeta_f[104]; dP = mymeta_f[208];
+        }
+      }
+      // no second barrier: the next write to a box comes from the slot that has just read it (see the header)
+    }
+    used_sweeps = sweep + 1;
+    if (rotated) s_flag[sweep & 1] = 1;
+    if (bigrot) s_flag[2 + (sweep & 1)] = 1;
+    lds_barrier();
+    const int any = s_flag[sweep & 1], anybig = s_flag[2 + (sweep & 1)];
+    if (tid == 0) { s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0; s_flag[4 + ((sweep + 1) & 1)] = 0; }
+    lds_barrier();
+    if (!any || !anybig) { converged = true; break; }
+  }
+
+  // ---- singular values = norms of the true columns over the first norm_rows rows; phantom columns rank last
+  fold(false, false);
+  exact_norms(norm_rows);
+  lds_barrier();                                   // every wave is out of the sweep loop (mailbox reads done)
+  if (live && sub < 4) {
+    s_sig[8 * k + q] = (idP >= n) ? -1.f : sqrtf(nP);
+    s_sig[8 * k + 4 + q] = (idQ >= n) ? -1.f : sqrtf(nQ);
+    s_pid[8 * k + q] = idP;
+    s_pid[8 * k + 4 + q] = idQ;
+  }
+  lds_barrier();
+  const int n_tot = 8 * S;                         // >= n; positions beyond the real columns hold -1
+  for (int p = tid; p < n_tot; p += blockDim.x) {
+    int rank = p;
+    if (sort) {
+      const float mine = s_sig[p];
+      rank = 0;
+      for (int c = 0; c < n_tot; ++c) {
+        const float o = s_sig[c];
+        rank += (o > mine) || (o == mine && c < p);
+      }
+    }
+    s_rank[p] = rank;
+  }
+  lds_barrier();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int idc = s_pid[8 * k + c];
+      const int d = sort ? s_rank[8 * k + c] : idc;
+      const float sg = s_sig[8 * k + c];
+      if (idc < n && d < n) {
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+          const int r = roff + 64 * ch;
+          if (r < ld) *reinterpret_cast<v4f*>(src + (size_t)d * ld + r) = (r < mr) ? C[c][ch] : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        if (sub == 0) sigma[(size_t)mat * n + d] = sg < 0.f ? 0.f : sg;
+      }
+    }
+  }
+  if (sweeps_out && tid == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
+  report_status(status, converged, s_sig, n_tot, tid, blockDim.x, 6, mat);
+}
+
 }  // namespace basd
 
 extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
@@ -817,6 +1237,28 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   // VGPRs (202 in all, no spills), seven waves, one workgroup per CU: 4.02 vs 5.00 ms per 512 matrices of 196 x 196
   // with the single-mailbox odd-even kernel
   const bool blk7 = oe_ch == 7 && n_cols <= 196;
+  {
+    // quad-block ordering with scaled rotations (BASD_JACOBI_B4=0 falls back to the block kernel below: A/B timing)
+    const char* b4env = getenv("BASD_JACOBI_B4");
+    const bool b4 = !(b4env && b4env[0] == '0');
+    if (b4 && (active == nullptr || mask_only) && batch >= 32 && n_cols <= 192 && n_cols >= 8 && chunks <= 6) {
+      const int nb4 = (n_cols + 3) / 4, slots4 = (nb4 + 1) / 2;
+      const int threads4 = ((slots4 * 16 + 63) / 64) * 64;
+      const int ch64 = (((m_rows + 3) & ~3) + 63) / 64;
+      const size_t lds4 = ((size_t)(slots4 + 1) * 4 * 64 * ch64 + 200 * 3 + 104 * 3 + 8) * 4;
+#define BASD_LAUNCH_B4(MC)                                                                           \
+  do {                                                                                               \
+    allow_full_lds((const void*)jacobi_b4_kernel<MC>);                                               \
+    hipLaunchKernelGGL((jacobi_b4_kernel<MC>), dim3(batch), dim3(threads4), lds4, st, w, batch, m_rows, n_cols, \
+                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status, active);         \
+  } while (0)
+      if (ch64 == 1) BASD_LAUNCH_B4(1);
+      else if (ch64 == 2) BASD_LAUNCH_B4(2);
+      else BASD_LAUNCH_B4(3);
+#undef BASD_LAUNCH_B4
+      return check_launch("jacobi_svd (quad-block, scaled rotations)");
+    }
+  }
   if ((active == nullptr || mask_only) && batch >= 32 && ((n_cols <= 192 && oe_ch <= 6) || blk7) && n_cols >= 8) {
     // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
     const int nbk = (n_cols + 1) / 2, slots = (nbk + 1) / 2;

@@ -78,6 +78,11 @@ class LocalImageSplit(Dataset):
     def __len__(self):
         return len(self.labels)
 
+    def set_epoch(self, epoch: int) -> None:
+        """forwarded to the per-sample transform (``Trainer.train`` calls it before every epoch)"""
+        if hasattr(self.transform, "set_epoch"):
+            self.transform.set_epoch(epoch)
+
     def image(self, i: int) -> torch.Tensor:
         if self.kind == "npz":
             arr = self.images[i]
@@ -172,7 +177,19 @@ class _DualView:
     (seed, e, i): reproducible whatever the worker count"""
 
     def __init__(self, clean_tf, aug_tf, seed: int):
-        self.clean_tf, self.aug_tf, self.seed, self.epoch = clean_tf, aug_tf, seed, 0
+        self.clean_tf, self.aug_tf, self.seed = clean_tf, aug_tf, seed
+        # the epoch lives in SHARED memory: DataLoader workers (persistent ones included) hold a pickled copy of this
+        # object, and a plain attribute set in the parent would never reach them -- every epoch would then replay the
+        # same crop / flip / TrivialAugment op for sample i (the reference draws fresh ones each epoch,
+        # src/data/datasets.py:137-149 with torchvision's global RNG)
+        self._epoch = torch.zeros(1, dtype=torch.int64).share_memory_()
+
+    @property
+    def epoch(self) -> int:
+        return int(self._epoch[0])
+
+    def set_epoch(self, epoch: int) -> None:
+        self._epoch[0] = int(epoch)
 
     def __call__(self, i: int, img: torch.Tensor, label: int):
         gen = torch.Generator().manual_seed((self.seed * 1_000_003 + self.epoch) * 2_000_003 + i)

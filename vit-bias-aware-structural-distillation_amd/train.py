@@ -14,6 +14,7 @@ from __future__ import annotations
 import argparse
 import math
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -148,9 +149,15 @@ def main(argv=None):
         # reference src/train.py:110-113: dual-view training batches (clean view normalised with the TEACHER's
         # statistics) + the evaluation loader, here from a local dataset root
         loader, val = create_dataloaders(config, teacher_stats=(trainer._teacher.mean, trainer._teacher.std))
-    elif config.data.dataset != "synthetic" and not os.environ.get("BASD_ALLOW_SYNTHETIC", "1") == "1":
-        raise SystemExit(f"data.dataset={config.data.dataset!r} is not a local directory (hub datasets need the network)")
+    elif config.data.dataset != "synthetic" and os.environ.get("BASD_ALLOW_SYNTHETIC", "0") != "1":
+        # never train on noise by accident: a dataset name that is not a local directory (the reference configurations
+        # name hub datasets) is an error unless synthetic data is asked for explicitly
+        raise SystemExit(f"data.dataset={config.data.dataset!r} is not a local directory (hub datasets need the network); "
+                         "use data.dataset=synthetic or BASD_ALLOW_SYNTHETIC=1 for synthetic batches")
     else:
+        if config.data.dataset != "synthetic":
+            print(f"WARNING: data.dataset={config.data.dataset!r} is not available locally; BASD_ALLOW_SYNTHETIC=1: training "
+                  "and evaluating on SYNTHETIC noise batches", file=sys.stderr)
         loader = SyntheticLoader(config.data.batch_size, config.model.vit.img_size, config.model.num_classes,
                                  args.steps_per_epoch, trainer.device)
     start_epoch = 0

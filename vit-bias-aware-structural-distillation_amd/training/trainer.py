@@ -12,6 +12,7 @@ for signature compatibility and may be None: mixed precision is
 from __future__ import annotations
 
 import collections
+import contextlib
 
 import os
 
@@ -105,9 +106,15 @@ class Trainer:
         self._seg_spec = None
         self._seg_pending = None
         self._seg_late = None
-        # backward in two stages with the late gradients all-reduced under the second one: whenever gradients are
-        # reduced at all (basd.segmented_backward forces it on a single rank: tests)
-        self.segmented = self.reducer.enabled or self._force_segmented
+        # backward in two stages with the late gradients all-reduced under the second one: OPT-IN
+        # (basd.segmented_backward: true).  The path has only ever run with gloo on CPU and on a single GPU rank, where
+        # the range all-reduce is a no-op: until one multi-GPU run has compared its gradients with the eager hook path,
+        # several ranks use the schedule that HAS been validated -- one captured graph, then one all-reduce of the flat
+        # gradient buffer (23 MB for the benchmarked student: ~0.15 ms on xGMI next to a ~36 ms step).
+        self.segmented = self._force_segmented
+        # debug check of the invariant the two-stage path rests on (stage 2 never writes the late slice of the flat
+        # gradient buffer): BASD_CHECK_SEGMENTS=1 compares the slice before / after the second replay
+        self._check_segments = os.environ.get("BASD_CHECK_SEGMENTS", "0") == "1"
         # Software pipelining of the frozen teacher ACROSS steps (captured steps only): while loss / backward of batch k
         # run, the side stream computes the teacher forward + selector statistics of batch k + 1 into the other of two
         # held sets, so the step never waits for the teacher and the latency-bound kernels of the loss no longer leave
@@ -123,9 +130,9 @@ class Trainer:
         # it ends, and the other stream's short kernels queue behind it (c2, same box: 41.3 ms per step against 39.5 with
         # workgroups that retire every two tiles; alone on the GPU the persistent form is the fastest: fc1 + GELU 288 vs
         # 327 us).  basd.gemm_tile_run overrides (0 = fully persistent).
-        if self.device.type == "cuda":
-            from .. import _native
-            _native.GEMM_TILE_RUN = int(config.basd.get("gemm_tile_run", 2))
+        # Scoped (``_tile_scope``): only steps that really run two streams see it; evaluation, inference and steps whose
+        # side stream was refused keep the fully persistent default.
+        self._gemm_tile_run = int(config.basd.get("gemm_tile_run", 2))
         self._graph_pool = None
         self._side = None
         self._graph = None
@@ -134,6 +141,15 @@ class Trainer:
         # pinned copies of the kernels' health word still in flight, oldest first: (event, host tensor); read late
         self._status_pending = collections.deque()
         self._status_free = []
+
+    def _tile_scope(self):
+        """context of a training step / a capture: the GEMM tile_run of the two-stream schedule while a side stream is in
+        use, the fully persistent kernels otherwise"""
+        if self.device.type != "cuda":
+            return contextlib.nullcontext()
+        from .. import _native
+        two_streams = self.overlap_teacher_stats and (self.overlap_teacher_forward or self.pipeline_teacher)
+        return _native.gemm_tile_run(self._gemm_tile_run if two_streams else 0)
 
     def _side_stream(self):
         if self.device.type != "cuda" or not self.overlap_teacher_stats:
@@ -395,6 +411,10 @@ class Trainer:
                       "blind": 0, "announced": None}
 
     def enable_graph(self, batch: dict, warmup: int = 3, pipeline: bool | None = None) -> bool:
+        with self._tile_scope():
+            return self._enable_graph(batch, warmup, pipeline)
+
+    def _enable_graph(self, batch: dict, warmup: int = 3, pipeline: bool | None = None) -> bool:
         """Capture teacher fwd + student fwd + loss + backward into ONE hipGraph (static input
         buffers).  A step then costs the host one graph launch instead of ~1 300 kernel launches:
         on a shared host the eager step (26 ms of Python/launch work on an idle CPU) becomes
@@ -527,11 +547,19 @@ class Trainer:
             return
         off = self._segment_spec()["offset"]
         self.reducer.reduce_range_async(off, self.flat.numel)
+        late_before = self.flat.grad[off:].clone() if self._check_segments and not self.reducer.enabled else None
         tail.replay()
+        if late_before is not None and not torch.equal(late_before, self.flat.grad[off:]):
+            raise RuntimeError("two-stage captured backward: stage 2 wrote into the late gradient slice "
+                               f"[{off}, {self.flat.numel}) that is being all-reduced under it")
         self.reducer.reduce_range_async(0, off)
         self.reducer.wait_ranges()
 
     def train_step(self, batch: dict, next_batch: dict | None = None):
+        with self._tile_scope():
+            return self._train_step(batch, next_batch)
+
+    def _train_step(self, batch: dict, next_batch: dict | None = None):
         """One optimisation step on a device-resident batch {"clean","augmented","label"}.  ``next_batch`` (optional):
         the batch the NEXT call will get -- with a captured, pipelined step its teacher forward runs under this step's
         loss and backward (its "clean" tensor must be the very object passed next time)."""
@@ -652,6 +680,10 @@ class Trainer:
         for epoch in range(start_epoch, num_epochs):
             self.optimizer.train()
             self.model.train()
+            # fresh augmentations every epoch: the dual-view dataset seeds sample i's RNG from (seed, epoch, i)
+            ds = getattr(train_loader, "dataset", None)
+            if hasattr(ds, "set_epoch"):
+                ds.set_epoch(epoch)
             metrics = self._train_epoch(train_loader)
             self.optimizer.eval()
             if evaluate_fn is not None and val_loader is not None:
