@@ -11,7 +11,7 @@ def timeit(f, it=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / it * 1e3
 
-for batch, n in [(1024, 192), (12, 192), (48, 64)]:
+for batch, n in [(1024, 192), (4, 192), (24, 192), (48, 192), (48, 64)]:
     g = torch.Generator().manual_seed(n)
     # cross-covariance-like: graded spectrum, condition ~1e5
     z = torch.randn(batch, 2 * n, n, dtype=torch.float64, generator=g) * torch.logspace(0, -2.5, n, dtype=torch.float64)

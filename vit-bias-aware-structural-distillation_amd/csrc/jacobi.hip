@@ -916,37 +916,48 @@ template <int MAXCH>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void jacobi_b4_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
     float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status,
-    const int32_t* __restrict__ skip) {
+    const int32_t* __restrict__ active, int active_mode) {
+  // active_mode 0: no `active`; 1: active[mat] = number of leading non-zero columns (the tournament runs over those,
+  // the other columns are zero and stay zero); 2: the same and only the leading active[mat] ROWS are non-zero;
+  // 3: `active` is a mask (< 0: skip the matrix, otherwise solve it completely)
   extern __shared__ __align__(16) float lds[];
-  if (skip != nullptr && skip[blockIdx.x] < 0) {   // masked problem: nothing is read or written
-    if (sweeps_out && threadIdx.x == 0) sweeps_out[blockIdx.x] = 0;
-    return;
+  const int mat = blockIdx.x;
+  int n_act = n;
+  if (active_mode != 0) {
+    const int av = active[mat];
+    if (active_mode == 3) {
+      if (av < 0) {                                // masked problem: nothing is read or written
+        if (sweeps_out && threadIdx.x == 0) sweeps_out[mat] = 0;
+        return;
+      }
+    } else {
+      n_act = av < 2 ? 2 : (av > n ? n : av);
+    }
   }
   constexpr int LDC = 64 * MAXCH;                  // one column in the mailbox
   constexpr int LDB = 4 * LDC;                     // one block
   const int tid = threadIdx.x;
   const int k = tid >> 4, sub = tid & 15, roff = sub * 4, q = sub & 3;
   const bool bit0 = (sub & 1) != 0, bit1 = (sub & 2) != 0;
-  const int nb = (n + 3) >> 2;                     // blocks that hold real columns
+  const int nb_all = (n + 3) >> 2;
+  const int S_all = (nb_all + 1) >> 1;             // slots the launch provides (threads / 16, rounded up to waves)
+  const int nb = (n_act + 3) >> 2;                 // blocks that hold active columns
   const int nbe = nb + (nb & 1);                   // line length in blocks (a zero phantom block pads odd nb)
-  const int S = nbe >> 1;                          // slots
-  float* mbox = lds;                               // [S + 1][LDB]
-  float* s_sig = mbox + (size_t)(S + 1) * LDB;     // [8 S] by position
-  int* s_rank = reinterpret_cast<int*>(s_sig + 200);      // [8 S]
-  int* s_pid = s_rank + 200;                       // [8 S] column id by position
-  int* s_id = s_pid + 200;                         // [S + 1][4] ids travelling with the mailbox
-  float* s_nrm = reinterpret_cast<float*>(s_id + 104);    // [S + 1][4] squared norms
-  float* s_scl = s_nrm + 104;                      // [S + 1][4] scales
+  const int S = nbe >> 1;                          // slots that take part
+  float* mbox = lds;                               // [S_all + 1][LDB]
+  float* s_sig = mbox + (size_t)(S_all + 1) * LDB; // [8 S_all] by position
+  int* s_rank = reinterpret_cast<int*>(s_sig + 200);      // [8 S_all]
+  float* s_nrm = reinterpret_cast<float*>(s_rank + 200);  // [S_all + 1][4] squared norms travelling with the mailbox
+  float* s_scl = s_nrm + 104;                      // [S_all + 1][4] scales
   int* s_flag = reinterpret_cast<int*>(s_scl + 104);      // [2] any rotation, [2] any LARGE rotation, [2] max norm
 
-  const int mat = blockIdx.x;
   float* src = wg + (size_t)mat * n * ld;
-  const int mr = (m + 3) & ~3;
+  int mr = (m + 3) & ~3;
+  if (active_mode == 2) { const int ma = (n_act + 3) & ~3; mr = ma < mr ? ma : mr; }
   const bool live = k < S;
   const bool last = k == S - 1;
   float* const mybox = mbox + (size_t)k * LDB + roff;          // box k, this lane's rows
-  int* const mymeta = s_id + 4 * k + q;                         // box k, this lane's column: id, +104 norm, +208 scale
-  float* const mymeta_f = reinterpret_cast<float*>(mymeta);
+  float* const mymeta = s_nrm + 4 * k + q;                      // box k, this lane's column: norm, +104 scale
   v4f C[8][MAXCH];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -954,12 +965,13 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch) {
       const int r = roff + 64 * ch;
-      C[c][ch] = (live && idc < n && r < mr) ? *reinterpret_cast<const v4f*>(src + (size_t)idc * ld + r)
-                                             : (v4f){0.f, 0.f, 0.f, 0.f};
+      C[c][ch] = (live && idc < n_act && r < mr) ? *reinterpret_cast<const v4f*>(src + (size_t)idc * ld + r)
+                                                 : (v4f){0.f, 0.f, 0.f, 0.f};
     }
   }
-  // distributed bookkeeping: lane q of every quad owns column q of block P (C[q]) and of block Q (C[4 + q])
-  int idP = 8 * k + q, idQ = 8 * k + 4 + q;
+  // distributed bookkeeping: lane q of every quad owns column q of block P (C[q]) and of block Q (C[4 + q]).
+  // Column ids are NOT carried: blocks move as wholes on a data-independent schedule -- a sweep of the odd-even
+  // transposition line reverses the block order, so after s sweeps position p holds block (s odd ? nbe - 1 - p : p).
   float nP = 0.f, nQ = 0.f, dP = 1.f, dQ = 1.f;
   if (tid < 8) s_flag[tid] = 0;
   __syncthreads();
@@ -976,7 +988,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float dx = meta_gather<M::gx, M::xq_mask>(dP, dQ, q), dy = meta_gather<M::gy, M::yq_mask>(dP, dQ, q);
     const float g = gt * dx * dy;                  // dot product of the true columns
     const float gsc = g * inv_tol;
-    const bool rot = ok & (gsc * gsc > fmaxf(al * be, BASD_JACOBI_TINY));
+    const float ab_ = al * be;
+    const bool rot = ok & (gsc * gsc > fmaxf(ab_, BASD_JACOBI_TINY));
     {
       // no branch around the rotation: a round in which all 16 rotations of the wave are below the threshold only
       // occurs on padded / rank-deficient columns (the solve stops after the first sweep of small rotations), and a
@@ -984,7 +997,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       // halves of the column registers across it); converged pairs run the shears with a = b = 0, an exact no-op
       rotated |= rot;
       const float gq = g * (1.0f / BASD_JACOBI_QUAD);
-      const bool big_cos = gq * gq > al * be;
+      const bool big_cos = gq * gq > ab_;
       const float z = (be - al) * __builtin_amdgcn_rcpf(2.f * g);
       float t = copysignf(1.f, z) * __builtin_amdgcn_rcpf(fabsf(z) + __builtin_amdgcn_sqrtf(fmaf(z, z, 1.f)));
       t = rot ? t : 0.f;
@@ -1085,7 +1098,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       round(RoundMap<0, 7, 1, 4, 2, 5, 3, 6>{}, pair_ok);
       // ---- hand one block over (positions swap after a meeting: the pair is then stored as lo = Q, hi = P).
       // ONE base address per lane for the boxes and one for their bookkeeping entries; everything else is an
-      // immediate offset (box k at 0, box k + 1 at LDB; ids / norms / scales 104 entries apart)
+      // immediate offset (box k at 0, box k + 1 at LDB; norms / scales 104 entries apart)
       if (even_view) {
         // Q (block position 2k) goes to slot k-1 through box k (slot 0's stays parked there); the last slot has no
         // right neighbour: it parks its P in box S and takes it back as Q (its lone block of the odd view)
@@ -1095,14 +1108,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + c * LDC + 64 * ch) = C[4 + c][ch];
           }
-          if (sub < 4) { mymeta[0] = idQ; mymeta_f[104] = nQ; mymeta_f[208] = dQ; }
+          if (sub < 4) { mymeta[0] = nQ; mymeta[104] = dQ; }
           if (last) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
               for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + 64 * ch) = C[c][ch];
             }
-            if (sub < 4) { mymeta[4] = idP; mymeta_f[104 + 4] = nP; mymeta_f[208 + 4] = dP; }
+            if (sub < 4) { mymeta[4] = nP; mymeta[104 + 4] = dP; }
           }
         }
         lds_barrier();
@@ -1112,7 +1125,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int ch = 0; ch < MAXCH; ++ch) C[4 + c][ch] = *reinterpret_cast<const v4f*>(mybox + LDB + c * LDC + 64 * ch);
           }
-          idQ = mymeta[4]; nQ = mymeta_f[104 + 4]; dQ = mymeta_f[208 + 4];
+          nQ = mymeta[4]; dQ = mymeta[104 + 4];
         }
       } else {
         // P (position 2k+2 after the swap) goes to slot k+1 through box k+1; slot 0 takes the parked block back
@@ -1122,7 +1135,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + 64 * ch) = C[c][ch];
           }
-          if (sub < 4) { mymeta[4] = idP; mymeta_f[104 + 4] = nP; mymeta_f[208 + 4] = dP; }
+          if (sub < 4) { mymeta[4] = nP; mymeta[104 + 4] = dP; }
         }
         lds_barrier();
         if (live) {
@@ -1131,7 +1144,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int ch = 0; ch < MAXCH; ++ch) C[c][ch] = *reinterpret_cast<const v4f*>(mybox + c * LDC + 64 * ch);
           }
-          idP = mymeta[0]; nP = mymeta_f[104]; dP = mymeta_f[208];
+          nP = mymeta[0]; dP = mymeta[104];
         }
       }
       // no second barrier: the next write to a box comes from the slot that has just read it (see the header)
@@ -1146,19 +1159,29 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (!any || !anybig) { converged = true; break; }
   }
 
-  // ---- singular values = norms of the true columns over the first norm_rows rows; phantom columns rank last
+  // ---- singular values = norms of the true columns over the first norm_rows rows
   fold(false, false);
   exact_norms(norm_rows);
   lds_barrier();                                   // every wave is out of the sweep loop (mailbox reads done)
-  if (live && sub < 4) {
-    s_sig[8 * k + q] = (idP >= n) ? -1.f : sqrtf(nP);
-    s_sig[8 * k + 4 + q] = (idQ >= n) ? -1.f : sqrtf(nQ);
-    s_pid[8 * k + q] = idP;
-    s_pid[8 * k + 4 + q] = idQ;
+  // The thread-derived indices are re-derived here from an opaque copy of the thread id: kept live across the sweep
+  // loop they cost registers the rotation rounds need (the allocator spills them into the inner loop otherwise).
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int k2 = tid2 >> 4, sub2 = tid2 & 15, q2 = sub2 & 3, roff2 = sub2 * 4;
+  const bool live2 = k2 < S;
+  // column ids by position: live slots hold block (sweeps odd ? nbe - 1 - p : p) at block position p; slots beyond
+  // the tournament never moved.  Ranking levels: active columns >= 0, inactive real columns -1, phantoms (id >= n) -2.
+  const bool odd = (used_sweeps & 1) != 0;
+  const int bP = live2 ? (odd ? nbe - 1 - 2 * k2 : 2 * k2) : 2 * k2;
+  const int bQ = live2 ? (odd ? nbe - 2 - 2 * k2 : 2 * k2 + 1) : 2 * k2 + 1;
+  if (k2 < S_all && sub2 < 4) {
+    const int idP = 4 * bP + q2, idQ = 4 * bQ + q2;
+    s_sig[8 * k2 + q2] = idP >= n ? -2.f : ((live2 && idP < n_act) ? sqrtf(nP) : -1.f);
+    s_sig[8 * k2 + 4 + q2] = idQ >= n ? -2.f : ((live2 && idQ < n_act) ? sqrtf(nQ) : -1.f);
   }
   lds_barrier();
-  const int n_tot = 8 * S;                         // >= n; positions beyond the real columns hold -1
-  for (int p = tid; p < n_tot; p += blockDim.x) {
+  const int n_tot = 8 * S_all;                     // >= n
+  for (int p = tid2; p < n_tot; p += blockDim.x) {
     int rank = p;
     if (sort) {
       const float mine = s_sig[p];
@@ -1171,24 +1194,24 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     s_rank[p] = rank;
   }
   lds_barrier();
-  if (live) {
+  if (k2 < S_all) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int idc = s_pid[8 * k + c];
-      const int d = sort ? s_rank[8 * k + c] : idc;
-      const float sg = s_sig[8 * k + c];
+      const int idc = 4 * (c < 4 ? bP : bQ) + (c & 3);
+      const int d = sort ? s_rank[8 * k2 + c] : idc;
+      const float sg = s_sig[8 * k2 + c];
       if (idc < n && d < n) {
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
-          const int r = roff + 64 * ch;
-          if (r < ld) *reinterpret_cast<v4f*>(src + (size_t)d * ld + r) = (r < mr) ? C[c][ch] : (v4f){0.f, 0.f, 0.f, 0.f};
+          const int r = roff2 + 64 * ch;
+          if (r < ld) *reinterpret_cast<v4f*>(src + (size_t)d * ld + r) = (live2 && r < mr) ? C[c][ch] : (v4f){0.f, 0.f, 0.f, 0.f};
         }
-        if (sub == 0) sigma[(size_t)mat * n + d] = sg < 0.f ? 0.f : sg;
+        if (sub2 == 0) sigma[(size_t)mat * n + d] = sg < 0.f ? 0.f : sg;
       }
     }
   }
-  if (sweeps_out && tid == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
-  report_status(status, converged, s_sig, n_tot, tid, blockDim.x, 6, mat);
+  if (sweeps_out && tid2 == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
+  report_status(status, converged, s_sig, n_tot, tid2, blockDim.x, 6, mat);
 }
 
 }  // namespace basd
@@ -1238,19 +1261,23 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
   // with the single-mailbox odd-even kernel
   const bool blk7 = oe_ch == 7 && n_cols <= 196;
   {
-    // quad-block ordering with scaled rotations (BASD_JACOBI_B4=0 falls back to the block kernel below: A/B timing)
+    // quad-block ordering with scaled rotations: every launch of up to 192 x 192 (BASD_JACOBI_B4=0 falls back to the
+    // kernels below: A/B timing).  BASD_JACOBI_B4_MIN sets the smallest batch it takes (default 1).
     const char* b4env = getenv("BASD_JACOBI_B4");
     const bool b4 = !(b4env && b4env[0] == '0');
-    if (b4 && (active == nullptr || mask_only) && batch >= 32 && n_cols <= 192 && n_cols >= 8 && chunks <= 6) {
+    const char* b4min = getenv("BASD_JACOBI_B4_MIN");
+    const int min_batch = b4min ? atoi(b4min) : 1;
+    if (b4 && batch >= min_batch && n_cols <= 192 && n_cols >= 8 && chunks <= 6) {
+      const int mode = active == nullptr ? 0 : (mask_only ? 3 : (active_rows ? 2 : 1));
       const int nb4 = (n_cols + 3) / 4, slots4 = (nb4 + 1) / 2;
       const int threads4 = ((slots4 * 16 + 63) / 64) * 64;
       const int ch64 = (((m_rows + 3) & ~3) + 63) / 64;
-      const size_t lds4 = ((size_t)(slots4 + 1) * 4 * 64 * ch64 + 200 * 3 + 104 * 3 + 8) * 4;
+      const size_t lds4 = ((size_t)(slots4 + 1) * 4 * 64 * ch64 + 200 * 2 + 104 * 2 + 8) * 4;
 #define BASD_LAUNCH_B4(MC)                                                                           \
   do {                                                                                               \
     allow_full_lds((const void*)jacobi_b4_kernel<MC>);                                               \
     hipLaunchKernelGGL((jacobi_b4_kernel<MC>), dim3(batch), dim3(threads4), lds4, st, w, batch, m_rows, n_cols, \
-                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status, active);         \
+                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status, active, mode);   \
   } while (0)
       if (ch64 == 1) BASD_LAUNCH_B4(1);
       else if (ch64 == 2) BASD_LAUNCH_B4(2);

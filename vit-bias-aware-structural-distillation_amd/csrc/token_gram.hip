@@ -361,6 +361,10 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
       }
     }
   }
+  // Measured and rejected (round 4): the partial tiles as plain stores into a workspace + a second launch that adds
+  // the 256 partial sets up (as the weight-gradient kernel does): 221 vs 174 us at 50 176 x 768 -> 192, 143 vs 100 us at
+  // d_in = 192 -- the fp64 atomics below are NOT what this kernel waits for -- and a scratch buffer shared by the
+  // teacher's and the student's launches chains the two streams of the step together.
 #pragma unroll
   for (int gi = 0; gi < GT_PER_WAVE; ++gi) {
     const int g = wave + gi * 4;
