@@ -20,6 +20,7 @@
  *                          matrix_norm(ord="nuc") src/losses/relational.py:48
  *   basd_mp_rank           layer_selector.py:17-20 (.median/.sum, on device, no .item())
  *   basd_angle_weights     layer_selector.py:100-108 (acos / spectral weighting / softmax over teacher layers)
+ *   basd_angle_weights_bwd autograd of layer_selector.py:86-108 (student frame, angles, softmax, temperatures)
  *   basd_mix_tokens        layer_selector.py:110-112 (+ torch.stack :128-129 eliminated)
  *   basd_procrustes_prep   src/losses/relational.py:29-46, src/losses/combined.py:9-14
  *   basd_mix_grad_dots     autograd of layer_selector.py:111-112 w.r.t. the mixing weights
@@ -31,6 +32,7 @@
  *   basd_transpose_bf16_table
  *                          the W^T operands autograd's nn.Linear backward forms per call (trainer.py:157)
  *   basd_procrustes_fwd    src/losses/relational.py:47-48 (cross-covariance, nuclear norm, U V^T) as one call
+ *   basd_procrustes_bwd    autograd of relational.py:29-48 (svd_backward of the nuclear norm + centring / weighting)
  *   basd_ce_uwso           nn.CrossEntropyLoss(label_smoothing) (trainer.py:47) + UW-SO (src/losses/combined.py:57,78-85)
  *   basd_wgrad_bf16        autograd of the student's timm nn.Linear layers (trainer.py:157)
  *   basd_sf_adamw_step     schedulefree.AdamWScheduleFree.step  src/training/trainer.py:54-58,158
@@ -189,6 +191,19 @@ int basd_flag_if_exceeds_f64(const double* values, int64_t n, double tol, int bi
 int basd_angle_weights(const float* sigma, const float* sw, const float* log_temp, int E, int L, int D,
                        int unnormalised, float* d2, float* pre, float* weights, float* coef, void* stream);
 
+/* Backward of the selector weights (autograd of src/losses/layer_selector.py:86-108 w.r.t. the student tokens and the
+ * temperatures).  g_w [E, L]: gradient w.r.t. the mixing weights; g_pre_out [E, L] (nullable): gradient w.r.t. the
+ * pre-softmax values; weights, d2 [E, L], log_temp [E]: forward values; t_seed [E, L, D, D] fp32: the forward's seeds
+ * A_full A_bar^T Phi (rows b >= k_j only); v_s [E, D, D] fp32 (rows = eigenvectors of the student's centred Gram),
+ * lam_s [E, D] fp64 (its eigenvalues); proj_s [D, D_s] fp32.  Outputs: g_log_temp [E] fp32, w_tok [E, D_s, D_s] fp32 with
+ * d loss / d s_i = (s_i - column mean) w_tok[i].  One reduction launch, four basd_bgemm_f64 products, one store, on a
+ * workspace of basd_angle_weights_bwd_workspace_bytes(E, D, D_s) bytes.  L <= 64. */
+int64_t basd_angle_weights_bwd_workspace_bytes(int E, int D, int D_s);
+int basd_angle_weights_bwd(const float* g_w, const float* g_pre_out, const float* weights, const float* d2,
+                           const float* log_temp, const float* t_seed, const float* v_s, const double* lam_s,
+                           const float* proj_s, int E, int L, int D, int D_s, float* g_log_temp, float* w_tok,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* mixed[i] = sum_j w[i, j] * x_j   (all E mixes from ONE pass over the teacher layers)
  * x_layers: HOST array of L device pointers to [elems] tensors (dtype code; the pointers are
  * passed to the kernel by value, no device-side table), w: [E, L] fp32,
@@ -340,6 +355,27 @@ int64_t basd_procrustes_workspace_bytes(int batch, int n, int d_s, int d_t);
 int basd_procrustes_fwd(const float* s_w, const float* t_w, int batch, int n, int d_s, int d_t, double tol,
                         float* nuc, float* fac_s, float* a_t, int32_t* status, void* workspace,
                         int64_t workspace_bytes, void* stream);
+
+/* Backward of the same term (autograd of src/losses/relational.py:29-48: svd_backward of the nuclear norm = the polar
+ * factor, then the centring / weighting), from the factors basd_procrustes_fwd saved.  Per side, with W the weighted
+ * tokens [batch, n, d] and fac [batch, n, n] (a_t for the teacher side, a_s for the student side of the token-side form):
+ *     out[b, i, :]  = 2 gl[b] sqrt(a[b, i]) (W - fac W)[b, i, :]        (fp32 or bf16)
+ *     rowdot[b, i]  = 2 gl[b] <(W - fac W)[b, i, :], W[b, i, :]>
+ * in one launch: the product runs on the bf16 matrix cores as a three-product split of both fp32 operands (relative
+ * error 2^-16), residual / scaling / row dots in its epilogue.  4 <= n <= 256, n % 4 == 0, d % 16 == 0, 16-byte
+ * aligned buffers. */
+int basd_procrustes_bwd_side(const float* fac, const float* w, const float* a, const float* gl, int batch, int n, int d,
+                             void* out, int out_dtype, float* rowdot, void* stream);
+
+/* The whole backward: s_w [batch, n, d_s], t_w [batch, n, d_t], a [batch, n] (basd_procrustes_prep outputs), gl [batch]
+ * (d loss / d value), fac_s / a_t (basd_procrustes_fwd outputs; fac_s is [batch, n, n] when n <= d_s, else
+ * [batch, n, d_s]) -> g_s [batch, n, d_s] (g_s_dtype: BASD_DTYPE_F32 | BASD_DTYPE_BF16), g_t [batch, n, d_t] fp32
+ * (gradients w.r.t. the RAW student tokens and the resampled teacher tokens), g_a [batch, n] (w.r.t. the normalised
+ * importance).  workspace: >= basd_procrustes_bwd_workspace_bytes(batch, n) bytes (the two row-dot vectors). */
+int64_t basd_procrustes_bwd_workspace_bytes(int batch, int n);
+int basd_procrustes_bwd(const float* s_w, const float* t_w, const float* a, const float* gl, const float* fac_s,
+                        const float* a_t, int batch, int n, int d_s, int d_t, void* g_s, int g_s_dtype, float* g_t,
+                        float* g_a, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Cross-entropy with label smoothing on soft targets [B, C] (MixUp / CutMix) or class indices [B] (exactly one of the
  * two non-NULL), its gradient, and the UW-SO combination with the Procrustes term (src/losses/combined.py:57,78-85;

@@ -989,3 +989,72 @@ def test_empty_batches_are_noops(nat):
     out, imp = nat.attention_fwd(torch.zeros(0, 197, 3 * 64, dtype=torch.bfloat16, device=dev), 1, 64, 0.125, True)
     assert out.shape == (0, 197, 64) and imp.shape == (0, 196)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("batch,n,d_s,d_t,s_dtype", [(6, 196, 192, 768, torch.bfloat16), (5, 196, 384, 1024, torch.float32),
+                                                     (7, 64, 192, 384, torch.bfloat16), (3, 16, 32, 64, torch.float32),
+                                                     (2, 52, 48, 80, torch.float32)])
+def test_procrustes_bwd_entry_matches_the_unfused_chain(nat, batch, n, d_s, d_t, s_dtype):
+    """basd_procrustes_bwd (one C call: the a_t t_w product as a bf16 three-product split with the residual / scaling /
+    row dots in its epilogue; feature side (n > d_s) and token side) against the fp64 arithmetic of
+    functional._ProcrustesFn.backward on the same factors"""
+    g = torch.Generator().manual_seed(batch * 1000 + n)
+    s_w = torch.randn(batch, n, d_s, generator=g).cuda()
+    t_w = torch.randn(batch, n, d_t, generator=g).cuda()
+    a = (torch.rand(batch, n, generator=g) + 0.1).cuda()
+    a = (a / a.sum(-1, keepdim=True)).contiguous()
+    gl = torch.randn(batch, generator=g).cuda()
+    a_t = (torch.randn(batch, n, n, generator=g) / n ** 0.5).cuda()
+    token_side = n <= d_s
+    fac_s = ((torch.randn(batch, n, n, generator=g) / n ** 0.5) if token_side else torch.randn(batch, n, d_s, generator=g)).cuda()
+    g_s, g_t, g_a = nat.procrustes_bwd(s_w, t_w, a, gl, fac_s, a_t, s_dtype)
+    torch.cuda.synchronize()
+    sw, tw, a64, gl64 = s_w.double(), t_w.double(), a.double(), gl.double()
+    p_t = a_t.double() @ tw
+    p_s = fac_s.double() @ sw if token_side else fac_s.double()
+    c = (2.0 * gl64).view(-1, 1, 1) * a64.sqrt().unsqueeze(-1)
+    want_t, want_s = c * (tw - p_t), c * (sw - p_s)
+    dot = (2.0 * gl64).view(-1, 1) * (((tw - p_t) * tw).sum(-1) + ((sw - p_s) * sw).sum(-1))
+    want_a = dot / (2.0 * a64)
+    assert g_s.dtype == s_dtype and g_t.dtype == torch.float32 and g_s.shape == s_w.shape and g_t.shape == t_w.shape
+    rel_t = float((g_t.double() - want_t).norm() / want_t.norm())
+    rel_s = float((g_s.double() - want_s).norm() / want_s.norm())
+    rel_a = float((g_a.double() - want_a).norm() / want_a.norm())
+    assert rel_t < 3e-5, rel_t                           # three-product bf16 split: 2^-16 of |A| |W|
+    assert rel_s < (5e-3 if s_dtype == torch.bfloat16 else 3e-5), rel_s
+    assert rel_a < 1e-4, rel_a
+    # element-wise: no entry is off by more than the split error of the product plus fp32 rounding
+    assert float((g_t.double() - want_t).abs().max()) <= 1e-4 * float(want_t.abs().max())
+
+
+@pytest.mark.parametrize("E,L,D,D_s,with_pre", [(4, 12, 192, 192, False), (2, 5, 64, 64, True), (3, 7, 48, 80, True)])
+def test_angle_weights_bwd_entry_matches_the_torch_chain(nat, E, L, D, D_s, with_pre):
+    """basd_angle_weights_bwd (one C call: layer reduction, eigenvalue-gap division, four fp64 products) against the
+    torch arithmetic of functional._SelectorWeightsFn.backward on the same saved tensors"""
+    g = torch.Generator().manual_seed(E * 100 + L)
+    g_w = torch.randn(E, L, generator=g).cuda()
+    g_pre_out = torch.randn(E, L, generator=g).cuda() if with_pre else None
+    wts = torch.softmax(torch.randn(E, L, generator=g), dim=1).cuda()
+    d2 = torch.rand(E, L, generator=g).cuda()
+    log_temp = torch.randn(E, generator=g).cuda()
+    t_seed = torch.randn(E, L, D, D, generator=g).cuda()
+    v_s = torch.linalg.qr(torch.randn(E, D, D, generator=g))[0].cuda()
+    lam_s = torch.sort(torch.rand(E, D, generator=g, dtype=torch.float64) + 0.01, descending=True).values.cuda()
+    lam_s[:, 3] = lam_s[:, 2]                                      # an exact tie: that entry of K is defined as 0
+    proj_s = torch.randn(D, D_s, generator=g).cuda()
+    g_lt, w_tok = nat.angle_weights_bwd(g_w, g_pre_out, wts, d2, log_temp, t_seed, v_s, lam_s, proj_s)
+    tau = torch.nn.functional.softplus(log_temp)
+    g_pre = wts * (g_w - (wts * g_w).sum(dim=1, keepdim=True))
+    if g_pre_out is not None:
+        g_pre = g_pre + g_pre_out
+    g_d2 = -g_pre / tau.unsqueeze(1)
+    want_lt = (g_pre * d2).sum(dim=1) / (tau * tau) * torch.sigmoid(log_temp)
+    c = (g_d2.unsqueeze(-1).unsqueeze(-1) * t_seed).sum(dim=1).double()
+    gap = lam_s.unsqueeze(1) - lam_s.unsqueeze(2)
+    k = torch.where(gap.abs() > 0, c / torch.where(gap.abs() > 0, gap, torch.ones_like(gap)), torch.zeros_like(c))
+    v64, p64 = v_s.double(), proj_s.double()
+    gg = v64.transpose(1, 2) @ k @ v64
+    want = (p64.t() @ (gg + gg.transpose(1, 2)) @ p64)
+    torch.testing.assert_close(g_lt, want_lt, rtol=2e-5, atol=1e-6)
+    rel = float((w_tok.double() - want).norm() / want.norm())
+    assert rel < 1e-5, rel

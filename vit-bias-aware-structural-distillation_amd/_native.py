@@ -13,7 +13,8 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbasd_hip.so")
+# BASD_LIB: an alternative build of the same library (A/B timing of kernel variants from scripts/); still no CPU path
+LIB_PATH = os.environ.get("BASD_LIB") or os.path.join(_HERE, "libbasd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F64 = 0, 1, 2
@@ -22,7 +23,9 @@ JACOBI_LDS_BYTES = 163840
 EXPORTS = (
     "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_flag_if_exceeds_f64", "basd_angle_weights", "basd_ce_uwso",
-    "basd_procrustes_workspace_bytes", "basd_procrustes_fwd", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
+    "basd_procrustes_workspace_bytes", "basd_procrustes_fwd", "basd_procrustes_bwd_side",
+    "basd_procrustes_bwd_workspace_bytes", "basd_procrustes_bwd", "basd_angle_weights_bwd_workspace_bytes",
+    "basd_angle_weights_bwd", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_bgemm_f64_masked", "basd_trinv_f64_masked", "basd_pchol_f64_masked", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
     "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_gemm_bf16x3_f32", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
     "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
@@ -49,6 +52,11 @@ _SIGNATURES = {
     "basd_mix_grad_dots": (_P, _I, _I, _I, _P, _I64, _I64, _I64, _P, _P),
     "basd_procrustes_workspace_bytes": (_I, _I, _I, _I),
     "basd_procrustes_fwd": (_P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _I64, _P),
+    "basd_procrustes_bwd_side": (_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P),
+    "basd_procrustes_bwd_workspace_bytes": (_I, _I),
+    "basd_angle_weights_bwd_workspace_bytes": (_I, _I, _I),
+    "basd_angle_weights_bwd": (_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I64, _P),
+    "basd_procrustes_bwd": (_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I64, _P),
     "basd_ce_uwso": (_P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P),
     "basd_transpose_bf16_table": (_P, _P, _P, _I, _P),
     "basd_bgemm_f64": (_P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _P, _I, _I64, _I, _I, _I, _I, _I, _I, _P),
@@ -428,6 +436,26 @@ def angle_weights(sigma: torch.Tensor, sw: torch.Tensor, log_temp: torch.Tensor,
     return d2, pre, wts, coef
 
 
+def angle_weights_bwd(g_w, g_pre_out, wts, d2, log_temp, t_seed, v_s, lam_s, proj_s):
+    """Backward of the selector weights as ONE C call (basd_angle_weights_bwd): -> (g_log_temp [E] fp32,
+    w_tok [E, D_s, D_s] fp32 with d loss / d s_i = (s_i - column mean) w_tok[i])."""
+    _need_cuda(g_w, wts, d2, log_temp, t_seed, v_s, lam_s, proj_s)
+    f32 = lambda t_: t_.detach().contiguous().float()
+    g_w, wts, d2, log_temp, t_seed, v_s, proj_s = map(f32, (g_w, wts, d2, log_temp, t_seed, v_s, proj_s))
+    g_pre_out = None if g_pre_out is None else f32(g_pre_out)
+    lam_s = lam_s.detach().contiguous().double()
+    e, l, d, _ = t_seed.shape
+    d_s = proj_s.shape[1]
+    assert proj_s.shape[0] == d and v_s.shape == (e, d, d) and lam_s.shape == (e, d) and g_w.shape == (e, l)
+    g_lt = torch.empty(e, dtype=torch.float32, device=g_w.device)
+    w_tok = torch.empty(e, d_s, d_s, dtype=torch.float32, device=g_w.device)
+    ws = torch.empty(int(lib().basd_angle_weights_bwd_workspace_bytes(e, d, d_s)), dtype=torch.uint8, device=g_w.device)
+    _check(lib().basd_angle_weights_bwd(_ptr(g_w), _ptr(g_pre_out), _ptr(wts), _ptr(d2), _ptr(log_temp), _ptr(t_seed),
+                                        _ptr(v_s), _ptr(lam_s), _ptr(proj_s), e, l, d, d_s, _ptr(g_lt), _ptr(w_tok),
+                                        _ptr(ws), ctypes.c_int64(ws.numel()), _stream()), "basd_angle_weights_bwd")
+    return g_lt, w_tok
+
+
 def _ptr_table(layers: list[torch.Tensor]):
     """Host array of device pointers (handed to the kernel by value: no H2D copy, graph-capturable)."""
     return (ctypes.c_void_p * len(layers))(*[t.data_ptr() for t in layers])
@@ -602,6 +630,32 @@ def procrustes_fwd(s_w: torch.Tensor, t_w: torch.Tensor, tol: float = 1e-13):
                                      ctypes.c_int64(ws.numel()), _stream()), "basd_procrustes_fwd")
     _scratch_used(rec)
     return nuc, fac_s, a_t
+
+
+def procrustes_bwd_supported(n: int, d_s: int, d_t: int) -> bool:
+    return 4 <= n <= 256 and n % 4 == 0 and d_t % 16 == 0 and d_t >= 16 and (n > d_s or (d_s % 16 == 0 and d_s >= 16)) and d_s % 4 == 0
+
+
+def procrustes_bwd(s_w: torch.Tensor, t_w: torch.Tensor, a: torch.Tensor, gl: torch.Tensor, fac_s: torch.Tensor,
+                   a_t: torch.Tensor, s_dtype=torch.float32):
+    """Backward of ``procrustes_fwd`` as ONE C call (basd_procrustes_bwd): -> (g_s [batch, n, d_s] in ``s_dtype``,
+    g_t [batch, n, d_t] fp32, g_a [batch, n] fp32).  The big product a_t t_w runs as a bf16 three-product split with the
+    residual / scaling / row dots in its epilogue."""
+    _need_cuda(s_w, t_w, a, gl, fac_s, a_t)
+    for t_ in (s_w, t_w, a, gl, fac_s, a_t):
+        assert t_.dtype == torch.float32 and t_.is_contiguous()
+    batch, n, d_s = s_w.shape
+    d_t = t_w.shape[2]
+    assert a_t.shape == (batch, n, n) and fac_s.shape == (batch, n, n if n <= d_s else d_s) and gl.numel() == batch
+    g_s = torch.empty(batch, n, d_s, dtype=s_dtype, device=s_w.device)
+    g_t = torch.empty(batch, n, d_t, dtype=torch.float32, device=s_w.device)
+    g_a = torch.empty(batch, n, dtype=torch.float32, device=s_w.device)
+    ws = torch.empty(int(lib().basd_procrustes_bwd_workspace_bytes(batch, n)), dtype=torch.uint8, device=s_w.device)
+    code = DTYPE_F32 if s_dtype == torch.float32 else DTYPE_BF16
+    _check(lib().basd_procrustes_bwd(_ptr(s_w), _ptr(t_w), _ptr(a), _ptr(gl), _ptr(fac_s), _ptr(a_t), batch, n, d_s, d_t,
+                                     _ptr(g_s), code, _ptr(g_t), _ptr(g_a), _ptr(ws), ctypes.c_int64(ws.numel()),
+                                     _stream()), "basd_procrustes_bwd")
+    return g_s, g_t, g_a
 
 
 def ce_uwso(logits: torch.Tensor, targets: torch.Tensor, smoothing: float, geo: torch.Tensor | None):

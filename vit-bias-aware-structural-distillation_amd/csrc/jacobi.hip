@@ -804,8 +804,9 @@ template <int CTRL> __device__ __forceinline__ int dppi(int v) {
 }
 __host__ __device__ constexpr int qperm(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 
-// lane (l & 3) = q of every quad receives sum over the 16 lanes of its row of p_q
-__device__ __forceinline__ float reduce_scatter4x16(float p0, float p1, float p2, float p3, bool bit0, bool bit1) {
+// lane (l & 3) = q of every quad receives the sum over the LANES (16: one DPP row, 32: two) lanes of its slot of p_q
+template <int LANES>
+__device__ __forceinline__ float reduce_scatter4(float p0, float p1, float p2, float p3, bool bit0, bool bit1) {
   const float keepA = bit0 ? p1 : p0, giveA = bit0 ? p0 : p1;
   const float keepB = bit0 ? p3 : p2, giveB = bit0 ? p2 : p3;
   const float uA = keepA + dppf<qperm(1, 0, 3, 2)>(giveA);
@@ -819,6 +820,13 @@ __device__ __forceinline__ float reduce_scatter4x16(float p0, float p1, float p2
   // 45-degree rotation, then differs between the rows of one column.)
   v += dppf<0x128>(v);                              // row_ror:8
   v += dppf<0x124>(v);                              // row_ror:4
+  if constexpr (LANES == 32) {
+    // the slot's two DPP rows: v_permlane16_swap with the same register as both operands leaves (row 0's value, row
+    // 1's value) in every lane of the row pair -- the same two operands in the same order in both rows
+    typedef unsigned int pl_u32x2 __attribute__((ext_vector_type(2)));
+    const pl_u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
   return v;
 }
 
@@ -912,8 +920,12 @@ template <int SCTRL, int YMASK> __device__ __forceinline__ float meta_scatter(fl
   }
 }
 
-template <int MAXCH>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void jacobi_b4_kernel(
+// LANES = lanes per slot: 16 (rows 4 sub + 64 ch) or 32 (rows 4 sub + 128 ch: columns of up to 384 rows at the same 96
+// column VGPRs, 768 threads -- the block pairs of the D_s = 384 eigensolver).  MAXCH = 4 at 16 lanes (193 .. 256 rows:
+// the 196 x 196 token-side Procrustes cores of the wide students) holds 128 column VGPRs: two waves per SIMD.
+template <int MAXCH, int LANES>
+__global__ __launch_bounds__(LANES == 32 ? 768 : (MAXCH > 3 ? 448 : 384))
+__attribute__((amdgpu_waves_per_eu((LANES == 16 && MAXCH > 3) ? 2 : 3, (LANES == 16 && MAXCH > 3) ? 2 : 3))) void jacobi_b4_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
     float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status,
     const int32_t* __restrict__ active, int active_mode) {
@@ -925,19 +937,17 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   int n_act = n;
   if (active_mode != 0) {
     const int av = active[mat];
-    if (active_mode == 3) {
-      if (av < 0) {                                // masked problem: nothing is read or written
-        if (sweeps_out && threadIdx.x == 0) sweeps_out[mat] = 0;
-        return;
-      }
-    } else {
-      n_act = av < 2 ? 2 : (av > n ? n : av);
+    if (av < 0) {                                  // masked problem (any mode): nothing is read or written
+      if (sweeps_out && threadIdx.x == 0) sweeps_out[mat] = 0;
+      return;
     }
+    if (active_mode != 3) n_act = av < 2 ? 2 : (av > n ? n : av);
   }
-  constexpr int LDC = 64 * MAXCH;                  // one column in the mailbox
+  constexpr int CHR = 4 * LANES;                   // rows of one chunk (4 per lane)
+  constexpr int LDC = CHR * MAXCH;                 // one column in the mailbox
   constexpr int LDB = 4 * LDC;                     // one block
   const int tid = threadIdx.x;
-  const int k = tid >> 4, sub = tid & 15, roff = sub * 4, q = sub & 3;
+  const int k = tid / LANES, sub = tid % LANES, roff = sub * 4, q = sub & 3;
   const bool bit0 = (sub & 1) != 0, bit1 = (sub & 2) != 0;
   const int nb_all = (n + 3) >> 2;
   const int S_all = (nb_all + 1) >> 1;             // slots the launch provides (threads / 16, rounded up to waves)
@@ -964,7 +974,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int idc = 8 * k + c;
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch) {
-      const int r = roff + 64 * ch;
+      const int r = roff + CHR * ch;
       C[c][ch] = (live && idc < n_act && r < mr) ? *reinterpret_cast<const v4f*>(src + (size_t)idc * ld + r)
                                                  : (v4f){0.f, 0.f, 0.f, 0.f};
     }
@@ -983,7 +993,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     using M = decltype(map);
     float p[4];
     dot4_cols<MAXCH>(C[M::X(0)], C[M::Y(0)], C[M::X(1)], C[M::Y(1)], C[M::X(2)], C[M::Y(2)], C[M::X(3)], C[M::Y(3)], p);
-    const float gt = reduce_scatter4x16(p[0], p[1], p[2], p[3], bit0, bit1);
+    const float gt = reduce_scatter4<LANES>(p[0], p[1], p[2], p[3], bit0, bit1);
     const float al = meta_gather<M::gx, M::xq_mask>(nP, nQ, q), be = meta_gather<M::gy, M::yq_mask>(nP, nQ, q);
     const float dx = meta_gather<M::gx, M::xq_mask>(dP, dQ, q), dy = meta_gather<M::gy, M::yq_mask>(dP, dQ, q);
     const float g = gt * dx * dy;                  // dot product of the true columns
@@ -1052,7 +1062,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       float a = 0.f;
 #pragma unroll
       for (int ch = 0; ch < MAXCH; ++ch) {
-        const int r = roff + 64 * ch;
+        const int r = roff + CHR * ch;
         const v4f x = C[c][ch];
         const float mx = (r + 0 < rows) ? 1.f : 0.f, my = (r + 1 < rows) ? 1.f : 0.f;
         const float mz = (r + 2 < rows) ? 1.f : 0.f, mw = (r + 3 < rows) ? 1.f : 0.f;
@@ -1060,8 +1070,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
       p[c] = a;
     }
-    nP = reduce_scatter4x16(p[0], p[1], p[2], p[3], bit0, bit1);
-    nQ = reduce_scatter4x16(p[4], p[5], p[6], p[7], bit0, bit1);
+    nP = reduce_scatter4<LANES>(p[0], p[1], p[2], p[3], bit0, bit1);
+    nQ = reduce_scatter4<LANES>(p[4], p[5], p[6], p[7], bit0, bit1);
   };
 
   int used_sweeps = 0;
@@ -1106,14 +1116,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + c * LDC + 64 * ch) = C[4 + c][ch];
+            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + c * LDC + CHR * ch) = C[4 + c][ch];
           }
           if (sub < 4) { mymeta[0] = nQ; mymeta[104] = dQ; }
           if (last) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
-              for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + 64 * ch) = C[c][ch];
+              for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + CHR * ch) = C[c][ch];
             }
             if (sub < 4) { mymeta[4] = nP; mymeta[104 + 4] = dP; }
           }
@@ -1123,7 +1133,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int ch = 0; ch < MAXCH; ++ch) C[4 + c][ch] = *reinterpret_cast<const v4f*>(mybox + LDB + c * LDC + 64 * ch);
+            for (int ch = 0; ch < MAXCH; ++ch) C[4 + c][ch] = *reinterpret_cast<const v4f*>(mybox + LDB + c * LDC + CHR * ch);
           }
           nQ = mymeta[4]; dQ = mymeta[104 + 4];
         }
@@ -1133,7 +1143,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + 64 * ch) = C[c][ch];
+            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + CHR * ch) = C[c][ch];
           }
           if (sub < 4) { mymeta[4] = nP; mymeta[104 + 4] = dP; }
         }
@@ -1142,7 +1152,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int ch = 0; ch < MAXCH; ++ch) C[c][ch] = *reinterpret_cast<const v4f*>(mybox + c * LDC + 64 * ch);
+            for (int ch = 0; ch < MAXCH; ++ch) C[c][ch] = *reinterpret_cast<const v4f*>(mybox + c * LDC + CHR * ch);
           }
           nP = mymeta[0]; dP = mymeta[104];
         }
@@ -1167,7 +1177,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // loop they cost registers the rotation rounds need (the allocator spills them into the inner loop otherwise).
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
-  const int k2 = tid2 >> 4, sub2 = tid2 & 15, q2 = sub2 & 3, roff2 = sub2 * 4;
+  const int k2 = tid2 / LANES, sub2 = tid2 % LANES, q2 = sub2 & 3, roff2 = sub2 * 4;
   const bool live2 = k2 < S;
   // column ids by position: live slots hold block (sweeps odd ? nbe - 1 - p : p) at block position p; slots beyond
   // the tournament never moved.  Ranking levels: active columns >= 0, inactive real columns -1, phantoms (id >= n) -2.
@@ -1203,7 +1213,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (idc < n && d < n) {
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
-          const int r = roff2 + 64 * ch;
+          const int r = roff2 + CHR * ch;
           if (r < ld) *reinterpret_cast<v4f*>(src + (size_t)d * ld + r) = (live2 && r < mr) ? C[c][ch] : (v4f){0.f, 0.f, 0.f, 0.f};
         }
         if (sub2 == 0) sigma[(size_t)mat * n + d] = sg < 0.f ? 0.f : sg;
@@ -1267,21 +1277,29 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     const bool b4 = !(b4env && b4env[0] == '0');
     const char* b4min = getenv("BASD_JACOBI_B4_MIN");
     const int min_batch = b4min ? atoi(b4min) : 1;
-    if (b4 && batch >= min_batch && n_cols <= 192 && n_cols >= 8 && chunks <= 6) {
+    const int rows4 = (m_rows + 3) & ~3;
+    const bool b4_16 = n_cols <= 196 && rows4 <= 256 && (rows4 <= 192 ? n_cols <= 192 : true);
+    const bool b4_32 = n_cols <= 192 && rows4 > 256 && rows4 <= 384;
+    if (b4 && batch >= min_batch && n_cols >= 8 && (b4_16 || b4_32)) {
       const int mode = active == nullptr ? 0 : (mask_only ? 3 : (active_rows ? 2 : 1));
+      const int lanes = b4_32 ? 32 : 16;
       const int nb4 = (n_cols + 3) / 4, slots4 = (nb4 + 1) / 2;
-      const int threads4 = ((slots4 * 16 + 63) / 64) * 64;
-      const int ch64 = (((m_rows + 3) & ~3) + 63) / 64;
-      const size_t lds4 = ((size_t)(slots4 + 1) * 4 * 64 * ch64 + 200 * 2 + 104 * 2 + 8) * 4;
-#define BASD_LAUNCH_B4(MC)                                                                           \
+      const int threads4 = ((slots4 * lanes + 63) / 64) * 64;
+      const int chn = (rows4 + 4 * lanes - 1) / (4 * lanes);
+      const size_t lds4 = ((size_t)(slots4 + 1) * 4 * 4 * lanes * chn + 200 * 2 + 104 * 2 + 8) * 4;
+      if (lds4 > BASD_JACOBI_LDS_BYTES)
+        return fail(BASD_ERR_SHAPE, "jacobi_svd: %d x %d needs %zu B of LDS", m_rows, n_cols, lds4);
+#define BASD_LAUNCH_B4(MC, LN)                                                                       \
   do {                                                                                               \
-    allow_full_lds((const void*)jacobi_b4_kernel<MC>);                                               \
-    hipLaunchKernelGGL((jacobi_b4_kernel<MC>), dim3(batch), dim3(threads4), lds4, st, w, batch, m_rows, n_cols, \
+    allow_full_lds((const void*)jacobi_b4_kernel<MC, LN>);                                           \
+    hipLaunchKernelGGL((jacobi_b4_kernel<MC, LN>), dim3(batch), dim3(threads4), lds4, st, w, batch, m_rows, n_cols, \
                        ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status, active, mode);   \
   } while (0)
-      if (ch64 == 1) BASD_LAUNCH_B4(1);
-      else if (ch64 == 2) BASD_LAUNCH_B4(2);
-      else BASD_LAUNCH_B4(3);
+      if (lanes == 32) BASD_LAUNCH_B4(3, 32);
+      else if (chn == 1) BASD_LAUNCH_B4(1, 16);
+      else if (chn == 2) BASD_LAUNCH_B4(2, 16);
+      else if (chn == 3) BASD_LAUNCH_B4(3, 16);
+      else BASD_LAUNCH_B4(4, 16);
 #undef BASD_LAUNCH_B4
       return check_launch("jacobi_svd (quad-block, scaled rotations)");
     }

@@ -84,6 +84,104 @@ extern "C" int basd_angle_weights(const float* sigma, const float* sw, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward of the selector weights (autograd of src/losses/layer_selector.py:86-108 w.r.t. the student tokens and the
+// temperatures) as ONE C entry.  From the forward's seeds T_ij = A_full A_bar^T Phi (rows b >= k_j) it forms, per
+// extraction point i,
+//     g_pre = w (g_w - <w, g_w>) (+ g_pre_out),   g_d2 = -g_pre / tau,   g_lt = sigmoid(lt) sum_j g_pre d2 / tau^2
+//     C_i   = sum_j g_d2_ij T_ij,   K_i[b, a] = C_i[b, a] / (lam_a - lam_b)      (0 where the gap is 0)
+//     G_i   = V_i^T K_i V_i,        W_i = P^T (G_i + G_i^T) P
+// so that d loss / d s_i = (s_i - mean) W_i.  One reduction kernel + four batched fp64 GEMMs (basd_bgemm_f64) + one
+// symmetrising store on a caller workspace; rounds 1 - 3 ran this block as ~15 torch launches.
+namespace basd {
+
+__global__ __launch_bounds__(256) void selector_bwd_seed_kernel(
+    const float* __restrict__ g_w, const float* __restrict__ g_pre_out, const float* __restrict__ wts,
+    const float* __restrict__ d2, const float* __restrict__ log_temp, const float* __restrict__ t_seed,
+    const double* __restrict__ lam, int L, int D, float* __restrict__ g_lt, double* __restrict__ k_out) {
+  __shared__ float s_gd2[64];
+  __shared__ float s_tau;
+  const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  if (tid == 0) {
+    const float lt = log_temp[i];
+    const float tau = lt > 20.f ? lt : log1pf(expf(lt));
+    float dotw = 0.f;
+    for (int j = 0; j < L; ++j) dotw += wts[i * L + j] * g_w[i * L + j];
+    float g_tau = 0.f;
+    for (int j = 0; j < L; ++j) {
+      float gp = wts[i * L + j] * (g_w[i * L + j] - dotw);
+      if (g_pre_out != nullptr) gp += g_pre_out[i * L + j];
+      s_gd2[j] = -gp / tau;
+      g_tau += gp * d2[i * L + j];
+    }
+    g_tau /= tau * tau;
+    if (b == 0) g_lt[i] = g_tau / (1.f + expf(-lt));
+    s_tau = tau;
+  }
+  __syncthreads();
+  const double lb = lam[(size_t)i * D + b];
+  for (int a = tid; a < D; a += 256) {
+    double c = 0.0;
+    for (int j = 0; j < L; ++j) c += (double)(s_gd2[j] * t_seed[(((size_t)i * L + j) * D + b) * D + a]);
+    const double gap = lam[(size_t)i * D + a] - lb;
+    k_out[((size_t)i * D + b) * D + a] = gap != 0.0 ? c / gap : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void symmetrise_store_kernel(const double* __restrict__ h, int n, float* __restrict__ out) {
+  const int i = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n * n) {
+    const int r = e / n, c = e - r * n;
+    out[(size_t)i * n * n + e] = (float)(h[(size_t)i * n * n + e] + h[(size_t)i * n * n + (size_t)c * n + r]);
+  }
+}
+
+}  // namespace basd
+
+extern "C" int64_t basd_angle_weights_bwd_workspace_bytes(int E, int D, int D_s) {
+  return (int64_t)E * ((int64_t)3 * D * D + (int64_t)D * D_s + (int64_t)D_s * D_s) * 8 + 1024;
+}
+
+extern "C" int basd_angle_weights_bwd(const float* g_w, const float* g_pre_out, const float* weights, const float* d2,
+                                      const float* log_temp, const float* t_seed, const float* v_s, const double* lam_s,
+                                      const float* proj_s, int E, int L, int D, int D_s, float* g_log_temp, float* w_tok,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+  using namespace basd;
+  if (E <= 0 || L <= 0) return BASD_OK;
+  if (L > 64 || D < 1 || D_s < 1) return fail(BASD_ERR_SHAPE, "angle_weights_bwd: L=%d (<= 64) D=%d D_s=%d", L, D, D_s);
+  if (workspace == nullptr || workspace_bytes < basd_angle_weights_bwd_workspace_bytes(E, D, D_s))
+    return fail(BASD_ERR_SHAPE, "angle_weights_bwd: workspace of %lld bytes, need %lld", (long long)workspace_bytes,
+                (long long)basd_angle_weights_bwd_workspace_bytes(E, D, D_s));
+  double* k = reinterpret_cast<double*>((((uintptr_t)workspace) + 255) & ~(uintptr_t)255);
+  double* kv = k + (size_t)E * D * D;            // K V
+  double* g = kv + (size_t)E * D * D;            // V^T K V
+  double* gp = g + (size_t)E * D * D;            // G P          [E, D, D_s]
+  double* h = gp + (size_t)E * D * D_s;          // P^T G P      [E, D_s, D_s]
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(selector_bwd_seed_kernel, dim3(E, D), dim3(256), 0, st, g_w, g_pre_out, weights, d2, log_temp,
+                     t_seed, lam_s, L, D, g_log_temp, k);
+  int rc = check_launch("angle_weights_bwd (seed reduction)");
+  if (rc) return rc;
+  const int64_t dd = (int64_t)D * D;
+  // K V:  [D, D] f64 x [D, D] f32
+  rc = basd_bgemm_f64(k, BASD_DTYPE_F64, dd, D, 0, v_s, BASD_DTYPE_F32, dd, D, 0, kv, BASD_DTYPE_F64, dd, D, E, D, D, D, 0, stream);
+  if (rc) return rc;
+  // V^T (K V)
+  rc = basd_bgemm_f64(v_s, BASD_DTYPE_F32, dd, D, 1, kv, BASD_DTYPE_F64, dd, D, 0, g, BASD_DTYPE_F64, dd, D, E, D, D, D, 0, stream);
+  if (rc) return rc;
+  // G P:  proj_s [D, D_s] shared by the batch (stride 0)
+  rc = basd_bgemm_f64(g, BASD_DTYPE_F64, dd, D, 0, proj_s, BASD_DTYPE_F32, 0, D_s, 0, gp, BASD_DTYPE_F64, (int64_t)D * D_s, D_s,
+                      E, D, D_s, D, 0, stream);
+  if (rc) return rc;
+  // P^T (G P)
+  rc = basd_bgemm_f64(proj_s, BASD_DTYPE_F32, 0, D_s, 1, gp, BASD_DTYPE_F64, (int64_t)D * D_s, D_s, 0, h, BASD_DTYPE_F64,
+                      (int64_t)D_s * D_s, D_s, E, D_s, D_s, D, 0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(symmetrise_store_kernel, dim3((D_s * D_s + 255) / 256, E), dim3(256), 0, st, h, D_s, w_tok);
+  return check_launch("angle_weights_bwd (symmetrise)");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Raise a status bit if any of n fp64 values is NOT <= tol (so a NaN raises it too), with an atomic OR: the health word
 // is shared with the kernels of the other stream, which atomicOr into it concurrently (a torch bitwise_or_ is a plain
 // read-modify-write and can lose their flag).

@@ -37,6 +37,9 @@ class BasdShapeError(NotImplementedError):
 # --------------------------------------------------------------------------- #
 # helpers
 # --------------------------------------------------------------------------- #
+# BASD_PROCRUSTES_BWD=lib: the Procrustes backward through the library fp32 bmm + basd_procrustes_bwd_rows (rounds 1 - 3)
+# instead of the one-call basd_procrustes_bwd (A/B timing)
+PROCRUSTES_BWD_FUSED = __import__("os").environ.get("BASD_PROCRUSTES_BWD", "fused") != "lib"
 WIDE_PANEL = 192          # widest eigenproblem of the LDS-resident Jacobi = panel of the blocked Cholesky
 WIDE_BLOCK = 96           # column block of the blocked Jacobi: a PAIR of blocks is one LDS-resident problem
 WIDE_COS_TOL = 1e-4      # columns of the blocked factor must end up orthogonal to this (else: NONCONVERGED flag)
@@ -473,6 +476,18 @@ class _SelectorWeightsFn(torch.autograd.Function):
     def backward(ctx, g_w, g_pre_out):
         log_temp, proj_s, wts, d2, tau, t_seed, v_s, lam_s, *student = ctx.saved_tensors
         E = ctx.n_student
+        ops = get_ops()
+        if getattr(ops, "angle_weights_bwd", None) is not None and wts.shape[1] <= 64 and ops.handles(t_seed):
+            # one C entry (basd_angle_weights_bwd): reduction over the teacher layers, eigenvalue-gap division and the
+            # four small fp64 products in six launches on a workspace
+            g_lt, w_tok = ops.angle_weights_bwd(g_w, g_pre_out, wts, d2, log_temp, t_seed, v_s, lam_s, proj_s)
+            g_lt = g_lt.to(log_temp.dtype)
+            grads = []
+            for i in range(E):
+                s = student[i]
+                centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
+                grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
+            return (g_lt, None, None, None, None, None, None, None, *grads)
         g_pre = wts * (g_w - (wts * g_w).sum(dim=1, keepdim=True))
         if g_pre_out is not None:
             g_pre = g_pre + g_pre_out
@@ -572,22 +587,25 @@ class _ProcrustesFn(torch.autograd.Function):
         n_s, n_t = s_w.shape[1], ctx.n_t
         ops = get_ops()
         gl = g_loss.float().reshape(-1).contiguous()
-        # residuals R = W - (other side) G^T, their scaling by 2 gl sqrt(a) and the row dots <R, W> that
-        # make up d loss / d a: one fused pass per side over the GEMM result
-        # the ONE declared library GEMM of the loss: a batched fp32 product of E B matrices [N, N] x [N, D_t] (60 GF at
-        # c2: 0.62 ms on the library's fp32-MFMA kernel; the own fp64-accumulated batched GEMM needs 1.3 ms, an own
-        # fp32-MFMA version measured 1.05 ms in round 2)
-        note_library_gemm("Procrustes backward: fp32 bmm (A_t t_w)")
-        if ctx.token_side:
-            p_s, p_t = polar[0] @ s_w, polar[1] @ t_w                # t_w G^T = A_s s_w, s_w G = A_t t_w
+        # residuals R = W - (other side) G^T, their scaling by 2 gl sqrt(a) and the row dots <R, W> that make up
+        # d loss / d a.  ONE C entry (basd_procrustes_bwd): the batched product a_t t_w (E B matrices [N, N] x [N, D_t],
+        # 60 GF at c2) runs as a bf16 three-product split on the matrix cores with the residual in its epilogue --
+        # rounds 1 - 3 used a library fp32 bmm (0.62 ms) plus a separate row pass here.
+        if PROCRUSTES_BWD_FUSED and getattr(ops, "procrustes_bwd_supported", None) is not None and \
+                ops.procrustes_bwd_supported(n_s, s_w.shape[2], t_w.shape[2]) and ctx.s_dtype in (torch.float32, torch.bfloat16):
+            g_s, g_t, g_a = ops.procrustes_bwd(s_w, t_w, a, gl, polar[0].contiguous(), polar[1].contiguous(), ctx.s_dtype)
         else:
-            # t_w G^T was formed in the forward (the fp32 row kernel below works in place: keep the saved copy
-            # intact for a second backward); s_w G = A_t t_w
-            p_s = polar[0].clone() if ctx.s_dtype == torch.float32 else polar[0]
-            p_t = polar[1] @ t_w
-        g_s, dot_s = ops.procrustes_bwd_rows(p_s, s_w, a, gl, out_dtype=ctx.s_dtype)
-        g_t, dot_t = ops.procrustes_bwd_rows(p_t, t_w, a, gl, out_dtype=torch.float32)
-        g_a = (dot_s + dot_t) / (2.0 * a)
+            note_library_gemm("Procrustes backward: fp32 bmm (A_t t_w)")
+            if ctx.token_side:
+                p_s, p_t = polar[0] @ s_w, polar[1] @ t_w                # t_w G^T = A_s s_w, s_w G = A_t t_w
+            else:
+                # t_w G^T was formed in the forward (the fp32 row kernel below works in place: keep the saved copy
+                # intact for a second backward); s_w G = A_t t_w
+                p_s = polar[0].clone() if ctx.s_dtype == torch.float32 else polar[0]
+                p_t = polar[1] @ t_w
+            g_s, dot_s = ops.procrustes_bwd_rows(p_s, s_w, a, gl, out_dtype=ctx.s_dtype)
+            g_t, dot_t = ops.procrustes_bwd_rows(p_t, t_w, a, gl, out_dtype=torch.float32)
+            g_a = (dot_s + dot_t) / (2.0 * a)
         imp = imp_all.float().reshape(-1, n_t)
         if n_t != n_s:
             r = resample_matrix(n_t, n_s, s_w.device)                  # [n_s, n_t]
