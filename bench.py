@@ -386,21 +386,23 @@ def main():
             traffic = None
             if big == 1024 and big_n == 192:      # the committed PMC passes were taken at this launch shape
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")) as f:
+                    with open(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")) as f:
                         for key, v in json.load(f)["kernels"].items():
-                            if key.startswith("basd::jacobi_blk_kernel<6>"):
+                            if key.startswith("basd::jacobi_b4_kernel<3") and key.endswith(f"grid={big * 384}"):
                                 traffic = v["hbm_bytes_per_launch"]
                 except OSError:
                     pass
-            kname = ("basd::jacobi_blk_kernel<6> (register-resident one-sided Jacobi, block odd-even ordering"
-                     if big >= 512 and big_n <= 192 else
-                     "basd::jacobi_oe_kernel (register-resident one-sided Jacobi, odd-even ordering")
+            kname = ("basd::jacobi_b4_kernel<3, 16> (register-resident one-sided Jacobi: quad-block odd-even ordering, scaled "
+                     "rotations" if big_n <= 192 else
+                     "basd::jacobi_b4_kernel<4, 16> (register-resident one-sided Jacobi: quad-block odd-even ordering, scaled "
+                     "rotations")
             roof = {"kernel": f"{kname}, the E*B = {big} Procrustes cores of a step, {big_n}x{big_n} each)",
                     # this kernel is VALU-issue-bound (neither of the contract's "hbm" | "mfma"): priced against the fp32
                     # vector peak, which equals the fp32 MFMA peak on gfx950 (157.3 TF)
                     "bound": "valu", "bound_detail": "fp32 VALU kernel priced against the fp32 vector peak (= fp32 MFMA peak, 157.3 TF/s); "
-                    "VALU-issue-bound (one workgroup per CU runs it as fast as two; 57 v_pk_fma_f32 + 22 v_fmac + ~20 other "
-                    "VALU instructions per rotation and wave) plus the hand-over chain of its 6 waves",
+                    "per round of four independent rotations and wave: 72 v_pk_fma_f32 (24 dot products + 48 shear updates) + ~75 "
+                    "other VALU instructions (reduce-scatter of the four dot products, ONE rotation-parameter stream for four "
+                    "rotations per slot, broadcasts), one LDS hand-over and one barrier per 16 rotations",
                     "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                     "frac": achieved / 157.3, "traffic": traffic,
                     "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / probe_steps,
@@ -410,11 +412,13 @@ def main():
                                     "basd_procrustes_fwd: the probe steps launch that entry's kernels one by one; "
                                     "rocprofv3 of the same command sees the graph-launched kernels: profiles/)"),
                     "mean_sweeps": sweep_sum / max(mats, 1),
-                    "traffic_source": "constant from the committed PMC passes (profiles/r03_pmc_hbm_traffic.json), not "
+                    "traffic_source": "constant from the committed PMC passes (profiles/r04_pmc_hbm_traffic.json), not "
                                       "measured in this run" if traffic is not None else None,
                     "note": "VALU kernel priced against the fp32 vector = matrix peak; algorithmic (textbook) "
-                            "flops = sweeps actually run (returned per matrix by the kernel) x n(n-1)/2 pairs x 14 m; the "
-                            "kernel EXECUTES ~10 m per pair (incremental norms), i.e. 0.71 x this figure (DESIGN.md section 5)"}
+                            "flops = sweeps actually run (returned per matrix by the kernel) x n(n-1)/2 pairs x 14 m (three "
+                            "dot products of length m + a four-FMA rotation of two columns); the kernel EXECUTES ~6 m per "
+                            "pair (one dot product by the incremental norms, two shears of 2 m instead of the 4 m rotation), "
+                            "i.e. 0.43 x this figure (DESIGN.md section 5)"}
         # ---- the kernel family with the largest TOTAL time: the bf16 GEMM of the ViT blocks (teacher forward, student
         # forward + input gradients), algorithmic flops 2 M N K over the device-event time of the same probe steps
         gemm = None

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-3 evidence: kernel traces (pipelined / per-step), PMC passes.  Run on the GPU box from the repo root.
+# round evidence (ROUND=r04 ...): kernel traces (pipelined / per-step), PMC passes.  Run on the GPU box from the repo root.
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${ROUND:-r03}
+O=$R/gpurun_out/${ROUND:-r04}
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for mode in pipelined unpipelined; do
@@ -20,7 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $(find $O/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_$c.csv
   rm -rf $O/pmc_$c
 done
-python3 $R/scripts/pmc_hbm_json.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/pmc_hbm_traffic.json
+python3 $R/scripts/pmc_hbm_json.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --eager --steps 2; bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB"
 rm -f $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/pmc_gemm -- python3 $R/scripts/time_gemm.py > $O/time_gemm_under_pmc.txt 2> $O/pmc_gemm.err
 echo "pmc gemm rc=$?"
@@ -32,4 +32,6 @@ python3 $R/scripts/pmc_summary.py $(find $O/pmc_jacobi -name "*counter_collectio
 rm -rf $O/pmc_jacobi
 python3 $R/scripts/time_gemm.py > $O/time_gemm.txt 2>&1
 python3 $R/scripts/time_jacobi.py > $O/time_jacobi.txt 2>&1
+python3 $R/scripts/time_procrustes_bwd.py > $O/time_procrustes_bwd.txt 2>&1
+python3 $R/scripts/time_token_gram.py > $O/time_token_gram.txt 2>&1
 ls -la $O
