@@ -361,7 +361,14 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
       }
     }
   }
-  // Measured and rejected (round 4): the partial tiles as plain stores into a workspace + a second launch that adds
+  // Measured / tried and rejected (round 4).
+  // (a) Two K chunks in flight (a second register set for the three P splits
+  // and the A fragments, loop unrolled by two): the kernel already fills 256 VGPRs + 154 AGPRs (96 projection + 160 Gram
+  // accumulators); the 44 extra registers make the allocator spill 237 -- not built further.  The projection loop stays
+  // bound by the L2 round trip of a 36 KiB chunk that has only the 72 MFMAs of ONE chunk (0.55 us) to hide under:
+  // 174 us per launch at 50 176 x 768 -> 192 against ~60 us of matrix work.  What would fix it: the P chunk through
+  // LDS-DMA (no staging registers), which needs the unpadded, source-swizzled LDS image of gemm_bf16.hip.
+  // (b) the partial tiles as plain stores into a workspace + a second launch that adds
   // the 256 partial sets up (as the weight-gradient kernel does): 221 vs 174 us at 50 176 x 768 -> 192, 143 vs 100 us at
   // d_in = 192 -- the fp64 atomics below are NOT what this kernel waits for -- and a scratch buffer shared by the
   // teacher's and the student's launches chains the two streams of the step together.
