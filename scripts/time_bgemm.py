@@ -20,6 +20,12 @@ cases = [  # name, a shape, a dtype, b shape, b dtype, trans_a, trans_b, out dty
     ("j1      linv wf^T", (B, 192, 192), f64, (B, 192, 192), f32, False, True, f64, False),
     ("theta   u^T j1^T ", (B, 192, 192), f32, (B, 192, 192), f64, True, True, f32, False),
     ("q2      linv cross", (B, 192, 192), f64, (B, 192, 768), f64, False, False, f32, False),
+    # the feature-side chain of basd_procrustes_fwd at c2 (round 4: 196 = 12.25 sub-tiles of 16)
+    ("Gt      t_w t_w^T sym", (B, 196, 768), f32, (B, 196, 768), f32, False, True, f64, True),
+    ("h       Gt s_w     ", (B, 196, 196), f64, (B, 196, 192), f32, False, False, f64, False),
+    ("gram    s_w^T h    ", (B, 196, 192), f32, (B, 196, 192), f64, True, False, f64, False),
+    ("fac_s   Gt pm^T    ", (B, 196, 196), f64, (B, 192, 196), f64, False, True, f32, False),
+    ("a_t     s_w pm     ", (B, 196, 192), f32, (B, 192, 196), f64, False, False, f32, False),
 ]
 tot = 0.0
 for name, sa, da, sb, db, ta, tb, do, sym in cases:

@@ -190,6 +190,18 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // 16 x 16 sub-tiles that need no MFMA (round 4): those entirely outside the matrix -- M = N = 196 is 12.25 sub-tiles:
+  // the fourth 64-row tile holds 4 valid rows, and with the padded tiles executed in full the symmetric Gram of the
+  // Procrustes chain did 160 sub-tile products per matrix for 91 useful ones -- and, in the diagonal tiles of a
+  // symmetric product, those strictly above the diagonal (mirrored from their transposes at the store).  Wave-uniform.
+  bool need[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r0 = m0 + wm + i * 16, c0 = n0 + wn + j * 16;
+      need[i][j] = r0 < M && c0 < N && !(sym && m0 == n0 && c0 > r0);
+    }
   // op(A) tile: TRA == 0 -> A is [M, K] (contiguous along k); TRA == 1 -> A is [K, M]
   // op(B) tile: TRB == 0 -> B is [K, N] (contiguous along the tile dim); TRB == 1 -> B is [N, K]
   typename Vec4<TA>::type ra = fetch4<TA, TRA>(A, lda, m0, M, 0, K, tid);
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+          if (need[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
       park4<TA, TRA>(ra, As[cur ^ 1], tid);
@@ -235,9 +247,10 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
       for (int reg = 0; reg < 4; ++reg) {
         const int r = m0 + wm + i * 16 + (lane >> 4) + 4 * reg;
         const int col = n0 + wn + j * 16 + (lane & 15);
-        if (r < M && col < N) {
+        if (need[i][j] && r < M && col < N) {
           C[(size_t)r * ldc + col] = (TC)acc[i][j][reg];
-          if (sym && n0 != m0) C[(size_t)col * ldc + r] = (TC)acc[i][j][reg];
+          // mirror: off-diagonal tiles, and the strictly lower sub-tiles of a diagonal tile
+          if (sym && (n0 != m0 || n0 + wn + j * 16 < m0 + wm + i * 16)) C[(size_t)col * ldc + r] = (TC)acc[i][j][reg];
         }
       }
 }
