@@ -1253,23 +1253,9 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     hipLaunchKernelGGL((jacobi_oe_kernel<MC, NM, (NM == 1 ? 2 : 1)>), dim3(GRID), dim3(threads), (LDSB), st, w, batch, m_rows, \
                        n_cols, ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows, status); \
   } while (0)
-  if (chunks > 7 && chunks <= 12 && npairs <= 96) {
-    // tall columns (up to 384 rows, at most 192 of them): single mailbox, 96 slots, 3 waves per SIMD
-    const size_t lds_tall = (size_t)npairs * 32 * 12 * 4 + oe_scratch;
-    allow_full_lds((const void*)jacobi_oe_kernel<12, 1, 1>);
-    hipLaunchKernelGGL((jacobi_oe_kernel<12, 1, 1>), dim3(batch), dim3(threads), lds_tall, st, w, batch, m_rows, n_cols, ld,
-                       norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows, status);
-    return check_launch("jacobi_svd (odd-even, tall columns)");
-  }
-  // (the block ordering also wins on small batches: 1.06 vs 1.27 ms at 48 matrices of 192^2, 1.27 vs 1.39 at 256,
-  // equal at 4 - 24: measured in round 3; before, it was only taken from 512 matrices up)
   // active_rows == 2: `active` is a MASK -- entries are either < 0 (skip the matrix) or n_cols (solve it completely)
   const bool mask_only = active != nullptr && active_rows == 2;
   if (mask_only) active_rows = 0;
-  // MAXCH = 7 (193 .. 224 rows, up to 196 columns: the 196-token Procrustes cores of the wide students): 112 column
-  // VGPRs (202 in all, no spills), seven waves, one workgroup per CU: 4.02 vs 5.00 ms per 512 matrices of 196 x 196
-  // with the single-mailbox odd-even kernel
-  const bool blk7 = oe_ch == 7 && n_cols <= 196;
   {
     // quad-block ordering with scaled rotations: every launch of up to 192 x 192 (BASD_JACOBI_B4=0 falls back to the
     // kernels below: A/B timing).  BASD_JACOBI_B4_MIN sets the smallest batch it takes (default 1).
@@ -1304,6 +1290,20 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
       return check_launch("jacobi_svd (quad-block, scaled rotations)");
     }
   }
+  if (chunks > 7 && chunks <= 12 && npairs <= 96) {
+    // tall columns (up to 384 rows, at most 192 of them): single mailbox, 96 slots, 3 waves per SIMD
+    const size_t lds_tall = (size_t)npairs * 32 * 12 * 4 + oe_scratch;
+    allow_full_lds((const void*)jacobi_oe_kernel<12, 1, 1>);
+    hipLaunchKernelGGL((jacobi_oe_kernel<12, 1, 1>), dim3(batch), dim3(threads), lds_tall, st, w, batch, m_rows, n_cols, ld,
+                       norm_rows, tol, max_sweeps, sort, sigma, sweeps, active, active_rows, status);
+    return check_launch("jacobi_svd (odd-even, tall columns)");
+  }
+  // (the block ordering also wins on small batches: 1.06 vs 1.27 ms at 48 matrices of 192^2, 1.27 vs 1.39 at 256,
+  // equal at 4 - 24: measured in round 3; before, it was only taken from 512 matrices up)
+  // MAXCH = 7 (193 .. 224 rows, up to 196 columns: the 196-token Procrustes cores of the wide students): 112 column
+  // VGPRs (202 in all, no spills), seven waves, one workgroup per CU: 4.02 vs 5.00 ms per 512 matrices of 196 x 196
+  // with the single-mailbox odd-even kernel
+  const bool blk7 = oe_ch == 7 && n_cols <= 196;
   if ((active == nullptr || mask_only) && batch >= 32 && ((n_cols <= 192 && oe_ch <= 6) || blk7) && n_cols >= 8) {
     // block ordering: one matrix per workgroup, slots = ceil(ceil(n / 2) / 2)
     const int nbk = (n_cols + 1) / 2, slots = (nbk + 1) / 2;
