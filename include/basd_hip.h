@@ -110,6 +110,13 @@ int basd_token_gram(const void* x, int x_dtype, int64_t rows, int d_in,
 int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_batch, int64_t batch_stride,
                            const void* proj_split, int d_out, double* gram, double* colsum, void* stream);
 
+/* Gram of a tall fp32 matrix z [rows, d] (row-major, 16-byte aligned, d % 16 == 0): gram [d, d] fp64 += z^T z (lower
+ * 16 x 16 tiles only), colsum [d] fp64 += column sums; both MUST be zeroed by the caller (atomics).  Tile-centred: per
+ * 64 rows the column means are subtracted, the centred tile runs on the fp32 matrix cores and the exact uncentred
+ * statistics are restored with fp64 rank-1 terms (the arithmetic of the fused kernel's Gram phase).  The statistics of
+ * src/losses/layer_selector.py:13,35 at student widths beyond 256 (BASELINE c4 / c5), after basd_gemm_bf16x3_f32. */
+int basd_gram_f32_centred(const float* z, int64_t rows, int d, double* gram, double* colsum, void* stream);
+
 /* Pivoted (diagonal pivoting) Cholesky of `batch` symmetric PSD fp64 matrices
  * a[b] (n x n).  Writes
  *   w0   [batch, n, ld] fp32: column k (contiguous, ld floats) = k-th Cholesky column,

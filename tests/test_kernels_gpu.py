@@ -1058,3 +1058,29 @@ def test_angle_weights_bwd_entry_matches_the_torch_chain(nat, E, L, D, D_s, with
     torch.testing.assert_close(g_lt, want_lt, rtol=2e-5, atol=1e-6)
     rel = float((w_tok.double() - want).norm() / want.norm())
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("rows,d,mean_scale", [(25088, 384, 0.0), (4100, 768, 30.0), (777, 400, 3.0), (64, 16, 0.0)])
+def test_gram_f32_centred_matches_fp64(nat, rows, d, mean_scale):
+    """basd_gram_f32_centred (tile-centred Gram of a tall fp32 matrix on the fp32 matrix cores, fp64 across the 64-row
+    tiles; the wide students' token statistics) against the fp64 product: lower triangle and column sums of the
+    UNCENTRED statistics, and the centred Gram formed from them the way the selector does -- also when the column means
+    are 30 x the spread (the case the tile centring exists for) and for a ragged last tile"""
+    import ctypes
+    g = torch.Generator().manual_seed(rows + d)
+    z = (torch.randn(rows, d, generator=g) + mean_scale * torch.randn(1, d, generator=g)).cuda()
+    gram = torch.zeros(d, d, dtype=torch.float64, device="cuda")
+    cs = torch.zeros(d, dtype=torch.float64, device="cuda")
+    rc = nat.lib().basd_gram_f32_centred(nat._ptr(z), ctypes.c_int64(rows), d, nat._ptr(gram), nat._ptr(cs), nat._stream())
+    assert rc == 0, nat.lib().basd_last_error()
+    z64 = z.double()
+    ref, refc = z64.t() @ z64, z64.sum(0)
+    low, rlow = torch.tril(gram), torch.tril(ref)
+    assert float((cs - refc).abs().max()) <= 1e-9 * float(refc.abs().max() + 1.0)
+    assert float((low - rlow).abs().max()) <= 2e-7 * float(ref.abs().max())
+    # the centred Gram (unc - s s^T / m): fp32-level accuracy relative to ITS scale, not the uncentred one's
+    full = low + torch.tril(gram, -1).t()
+    cen = full - cs.unsqueeze(1) * cs.unsqueeze(0) / rows
+    zc = z64 - z64.mean(0, keepdim=True)
+    rcen = zc.t() @ zc
+    assert float((cen - rcen).abs().max()) <= 5e-6 * float(rcen.abs().max())

@@ -21,7 +21,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F64 = 0, 1, 2
 JACOBI_LDS_BYTES = 163840
 
 EXPORTS = (
-    "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_pchol_f64", "basd_jacobi_svd",
+    "basd_version", "basd_last_error", "basd_token_gram", "basd_token_gram_bf16x3", "basd_gram_f32_centred", "basd_pchol_f64", "basd_jacobi_svd",
     "basd_mp_rank", "basd_flag_if_exceeds_f64", "basd_angle_weights", "basd_ce_uwso",
     "basd_procrustes_workspace_bytes", "basd_procrustes_fwd", "basd_procrustes_bwd_side",
     "basd_procrustes_bwd_workspace_bytes", "basd_procrustes_bwd", "basd_angle_weights_bwd_workspace_bytes",
@@ -39,6 +39,7 @@ _SIGNATURES = {
     "basd_last_error": (),
     "basd_token_gram": (_P, _I, _I64, _I, _I, _I64, _P, _I, _P, _P, _P),
     "basd_token_gram_bf16x3": (_P, _I64, _I, _I, _I64, _P, _I, _P, _P, _P),
+    "basd_gram_f32_centred": (_P, _I64, _I, _P, _P, _P),
     "basd_pchol_f64": (_P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P),
     "basd_pchol_f64_masked": (_P, _I, _I, _D, _P, _P, _I, _P, _P, _P, _P, _P),
     "basd_trinv_f64": (_P, _P, _P, _I, _I, _P, _P),
@@ -282,6 +283,10 @@ def _split_rows(m: int) -> int:
     return 1
 
 
+# BASD_WIDE_GRAM=f64: the split-K fp64-MFMA Gram of rounds 2 - 3 instead of basd_gram_f32_centred (A/B timing)
+WIDE_GRAM_FP32 = os.environ.get("BASD_WIDE_GRAM", "f32c") != "f64"
+
+
 def _token_gram_wide(x: torch.Tensor, proj: torch.Tensor):
     """d_out > 256 (student widths 384 / 768, BASELINE c4 / c5): the fused one-pass kernel keeps a [128, d_out] z tile
     and d_out^2 / 256 fp64 accumulator tiles on chip, which stops at 256 columns.  Here z = X P^T is materialised in
@@ -296,6 +301,14 @@ def _token_gram_wide(x: torch.Tensor, proj: torch.Tensor):
     else:
         z = bgemm_f64(x2.float().unsqueeze(0), proj.unsqueeze(0), trans_b=True, out_dtype=torch.float32)[0]
     m, d = z.shape
+    if WIDE_GRAM_FP32 and d % 16 == 0:
+        # round 4: tile-centred Gram on the fp32 matrix cores, fp64 across the 64-row tiles (basd_gram_f32_centred)
+        z = z.contiguous()
+        gram = torch.zeros(d, d, dtype=torch.float64, device=z.device)
+        colsum = torch.zeros(d, dtype=torch.float64, device=z.device)
+        _check(lib().basd_gram_f32_centred(_ptr(z), ctypes.c_int64(m), d, _ptr(gram), _ptr(colsum), _stream()),
+               "basd_gram_f32_centred")
+        return _mirror_lower(gram), colsum
     s = _split_rows(m)
     zs = z.view(s, m // s, d)
     gram = bgemm_f64(zs, zs, trans_a=True, symmetric=True).sum(dim=0)              # [d, d] fp64

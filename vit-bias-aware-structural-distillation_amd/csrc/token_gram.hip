@@ -422,3 +422,168 @@ extern "C" int basd_token_gram_bf16x3(const void* x, int64_t rows, int d_in, int
   }
   return check_launch("token_gram_bf16x3");
 }
+
+// --------------------------------------------------------------------------------------------
+// Gram of a tall fp32 matrix at student widths beyond the fused kernel's 256 columns (round 4; BASELINE c4 / c5:
+// z = X P^T [rows, 384 | 768] is materialised by basd_gemm_bf16x3_f32, z^T z ran as a split-K batched fp64-MFMA GEMM:
+// 1.5 ms per layer at c5, 54 ms per step).  Same arithmetic as the Gram phase of token_gram_bf16x3_kernel: per tile of
+// 64 rows the column means are subtracted, the centred tile is multiplied on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32, exact products, fp32 sums over 64 rows), and the exact uncentred statistics are restored
+// with the fp64 rank-1 terms  sum z z^T = G_c + mu w^T + w mu^T,  w = s - (n / 2) mu;  everything is added up in fp64.
+//
+// A workgroup (4 waves) owns a 128 x 128 block (I, J) of the lower block triangle and a slice of the rows; per row tile
+// it stages the two 64 x 128 column panels in LDS (prefetched into registers one tile ahead), every thread sums one of
+// the 256 staged columns (fp64), wave w multiplies the sub-tile rows {2 w, 2 w + 1} x all eight sub-tile columns (the
+// means are subtracted on the fragment reads: no centring pass), and the 16 fp64 accumulator tiles per wave (128 VGPRs)
+// persist over the whole row slice; one fp64 atomic per element and workgroup at the end (row slices: ~12 per block).
+namespace basd {
+
+constexpr int GW_TR = 64;             // rows per tile
+constexpr int GW_BC = 128;            // columns per panel
+constexpr int GW_LD = GW_BC + 16;     // floats per staged row: 144 = 16 (mod 32): the four k rows of a fragment read
+                                      // fall on different halves of the 32 banks (132 made every read 2-way)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_wide_f32_kernel(const float* __restrict__ z, int64_t rows, int d, int nbc,
+                                                            int rsplit, double* __restrict__ gram,
+                                                            double* __restrict__ colsum) {
+  extern __shared__ __align__(16) float gw_lds[];
+  float* Pi = gw_lds;                                  // [GW_TR][GW_LD] panel I (output rows)
+  float* Pj = Pi + GW_TR * GW_LD;                      // [GW_TR][GW_LD] panel J (output columns); == Pi on the diagonal
+  float* mu = Pj + GW_TR * GW_LD;                      // [256] fp32 tile means (I then J)
+  double* wv = reinterpret_cast<double*>(mu + 256);    // [256] fp64 w = s - (n / 2) mu
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // block (bi >= bj) of the lower block triangle and the row slice of this workgroup
+  const int blk = blockIdx.x / rsplit, rs = blockIdx.x - blk * rsplit;
+  int bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+  const int bj = blk - bi * (bi + 1) / 2;
+  const bool diag = bi == bj;
+  const int ci0 = bi * GW_BC, cj0 = bj * GW_BC;
+  const int64_t ntile = (rows + GW_TR - 1) / GW_TR;
+  const int64_t t_lo = ntile * rs / rsplit, t_hi = ntile * (rs + 1) / rsplit;
+  f64x4 acc[2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  double csum = 0.0;
+  // staging: thread -> (row = tid >> 5 (+ 8 per pass), column quad = tid & 31) of a panel: 8 passes of 16-byte loads
+  const int sr = tid >> 5, sq = tid & 31;
+  float4 pre_i[8], pre_j[8];
+  auto fetch = [&](int64_t tile) {
+    const int64_t r0 = tile * GW_TR;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int64_t r = r0 + sr + 8 * p;
+      const bool ok = r < rows;
+      const float* src = z + (ok ? r : 0) * (int64_t)d;
+      const bool oki = ok && ci0 + 4 * sq < d, okj = ok && cj0 + 4 * sq < d;
+      pre_i[p] = oki ? *reinterpret_cast<const float4*>(src + ci0 + 4 * sq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!diag) pre_j[p] = okj ? *reinterpret_cast<const float4*>(src + cj0 + 4 * sq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  for (int64_t tile = t_lo; tile < t_hi; ++tile) {
+    // two workgroups per CU: while this one waits for its panels (global -> registers -> LDS) the other one multiplies
+    // (a register prefetch across the MFMA phase costs 64 VGPRs, i.e. the second workgroup)
+    fetch(tile);
+    __syncthreads();                                   // the previous tile's fragment reads are done
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      *reinterpret_cast<float4*>(Pi + (sr + 8 * p) * GW_LD + 4 * sq) = pre_i[p];
+      if (!diag) *reinterpret_cast<float4*>(Pj + (sr + 8 * p) * GW_LD + 4 * sq) = pre_j[p];
+    }
+    __syncthreads();
+    const int64_t left = rows - tile * GW_TR;
+    const int nvalid = left < GW_TR ? (int)left : GW_TR;
+    {
+      // thread t < 128: column t of panel I, t >= 128: column t - 128 of panel J (the same panel on the diagonal)
+      const float* col = (tid < 128 ? Pi : (diag ? Pi : Pj)) + (tid & 127);
+      double s = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < GW_TR; ++r) s += (double)col[r * GW_LD];
+      const float m_ = (float)(s / (double)nvalid);
+      mu[tid] = m_;
+      wv[tid] = s - 0.5 * (double)nvalid * (double)m_;
+      if (diag && tid < 128) csum += s;
+    }
+    __syncthreads();
+    const float* Pjj = diag ? Pi : Pj;
+    const int li = lane & 15, kq = lane >> 4;
+    const bool partial = nvalid < GW_TR;               // uniform: only the last tile of the matrix
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int it = 2 * wave + a;                     // sub-tile row of the block
+      const float mi = mu[it * 16 + li];
+      float af[GW_TR / 4];
+#pragma unroll
+      for (int kk = 0; kk < GW_TR / 4; ++kk) {
+        const int r = kk * 4 + kq;
+        const float v = Pi[r * GW_LD + it * 16 + li] - mi;
+        af[kk] = (partial && r >= nvalid) ? 0.f : v;
+      }
+      double mi_r[4], wi_r[4];                         // rank-1 terms of this lane's four rows of sub-tile row `it`
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) { mi_r[reg] = (double)mu[it * 16 + 4 * kq + reg]; wi_r[reg] = wv[it * 16 + 4 * kq + reg]; }
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {                 // sub-tile columns in pairs: two independent MFMA chains
+        const int j0 = 2 * jp, j1 = 2 * jp + 1;
+        if (diag && j0 > it) continue;                 // strictly upper sub-tiles of a diagonal block: never stored
+        const bool use1 = !(diag && j1 > it);
+        const float mj0 = mu[128 + j0 * 16 + li], mj1 = mu[128 + j1 * 16 + li];
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < GW_TR / 4; ++kk) {
+          const int r = kk * 4 + kq;
+          float b0 = Pjj[r * GW_LD + j0 * 16 + li] - mj0, b1 = Pjj[r * GW_LD + j1 * 16 + li] - mj1;
+          if (partial && r >= nvalid) { b0 = 0.f; b1 = 0.f; }
+          t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], b0, t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], b1, t1, 0, 0, 0);
+        }
+        // t[reg] = G_c[row 4 kq + reg of sub-tile it][column li of sub-tile j]; + mu_i w_j + w_i mu_j in fp64
+        const double wj0 = wv[128 + j0 * 16 + li], wj1 = wv[128 + j1 * 16 + li];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          acc[a][j0][reg] += (double)t0[reg] + mi_r[reg] * wj0 + wi_r[reg] * (double)mj0;
+          if (use1) acc[a][j1][reg] += (double)t1[reg] + mi_r[reg] * wj1 + wi_r[reg] * (double)mj1;
+        }
+      }
+    }
+  }
+  // ---- add the workgroup's block into the caller's (zeroed / accumulating) Gram: lower 16 x 16 tiles only
+  const int li = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int it = 2 * wave + a;
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+      if (diag && jt > it) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int gi = ci0 + it * 16 + 4 * kq + reg, gj = cj0 + jt * 16 + li;
+        if (gi < d && gj < d) atomicAdd(&gram[(size_t)gi * d + gj], acc[a][jt][reg]);
+      }
+    }
+  }
+  if (diag && tid < 128 && ci0 + tid < d) atomicAdd(&colsum[ci0 + tid], csum);
+}
+
+}  // namespace basd
+
+extern "C" int basd_gram_f32_centred(const float* z, int64_t rows, int d, double* gram, double* colsum, void* stream) {
+  using namespace basd;
+  if (rows <= 0) return BASD_OK;
+  if (d < 16 || d % 16 || d > 4096 || (((uintptr_t)z) & 15))
+    return fail(BASD_ERR_SHAPE, "gram_f32_centred: need d %% 16 == 0, 16 <= d <= 4096, 16-byte aligned z (d=%d)", d);
+  const int nbc = (d + GW_BC - 1) / GW_BC;
+  const int nblk = nbc * (nbc + 1) / 2;
+  const int64_t ntile = (rows + GW_TR - 1) / GW_TR;
+  int rsplit = 512 / nblk;                              // two workgroups per CU, ONE round (273 workgroups on 256 CUs at one
+                                                        // per CU ran the launch twice as long as 252)
+  if ((int64_t)rsplit > ntile / 8) rsplit = (int)(ntile / 8);   // >= 8 row tiles per slice: a slice ends in 16 k fp64 atomics
+  if (rsplit < 1) rsplit = 1;
+  const size_t lds = (size_t)2 * GW_TR * GW_LD * 4 + 256 * 4 + 256 * 8;
+  allow_full_lds((const void*)gram_wide_f32_kernel);
+  hipLaunchKernelGGL(gram_wide_f32_kernel, dim3(nblk * rsplit), dim3(256), lds, (hipStream_t)stream, z, rows, d, nbc,
+                     rsplit, gram, colsum);
+  return check_launch("gram_f32_centred");
+}
