@@ -388,11 +388,11 @@ def main():
                 try:
                     with open(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")) as f:
                         for key, v in json.load(f)["kernels"].items():
-                            if key.startswith("basd::jacobi_b4_kernel<3") and key.endswith(f"grid={big * 384}"):
+                            if key.startswith("basd::jacobi_b6_kernel<3") and key.endswith(f"grid={big * 256}"):
                                 traffic = v["hbm_bytes_per_launch"]
                 except OSError:
                     pass
-            kname = ("basd::jacobi_b4_kernel<3, 16> (register-resident one-sided Jacobi: quad-block odd-even ordering, scaled "
+            kname = ("basd::jacobi_b6_kernel<3, 2> (register-resident one-sided Jacobi: hex-block odd-even ordering, scaled "
                      "rotations" if big_n <= 192 else
                      "basd::jacobi_b4_kernel<4, 16> (register-resident one-sided Jacobi: quad-block odd-even ordering, scaled "
                      "rotations")
@@ -400,9 +400,10 @@ def main():
                     # this kernel is VALU-issue-bound (neither of the contract's "hbm" | "mfma"): priced against the fp32
                     # vector peak, which equals the fp32 MFMA peak on gfx950 (157.3 TF)
                     "bound": "valu", "bound_detail": "fp32 VALU kernel priced against the fp32 vector peak (= fp32 MFMA peak, 157.3 TF/s); "
-                    "per round of four independent rotations and wave: 72 v_pk_fma_f32 (24 dot products + 48 shear updates) + ~75 "
-                    "other VALU instructions (reduce-scatter of the four dot products, ONE rotation-parameter stream for four "
-                    "rotations per slot, broadcasts), one LDS hand-over and one barrier per 16 rotations",
+                    "per round of six independent rotations and wave: 108 v_pk_fma/mul_f32 (36 dot-product + 72 shear updates) + "
+                    "~115 other instructions (reduce-scatter of the six dot products, ONE rotation-parameter stream for six "
+                    "rotations per slot, 16 LDS-crossbar moves), one LDS hand-over and one barrier per 36 rotations; four "
+                    "waves per matrix, two matrices per CU",
                     "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                     "frac": achieved / 157.3, "traffic": traffic,
                     "avg_launch_ms": tot_ms / launches, "launches_per_step": launches / probe_steps,

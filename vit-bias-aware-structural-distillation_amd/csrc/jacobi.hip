@@ -1224,6 +1224,417 @@ __attribute__((amdgpu_waves_per_eu((LANES == 16 && MAXCH > 3) ? 2 : 3, (LANES ==
   report_status(status, converged, s_sig, n_tot, tid2, blockDim.x, 6, mat);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hex-block ordering (round 4, second step): blocks of SIX columns, 16 slots of 16 lanes for 192 columns -- FOUR
+// waves, one per SIMD.  What the quad-block kernel leaves on the table: its 24 slots are six waves on four SIMDs
+// (two SIMDs carry two waves, two carry one: the workgroup runs at the pace of the loaded pair), and one
+// parameter stream serves four rotations.  Here a meeting of two blocks is 36 cross rotations in six rounds of SIX
+// independent rotations (one hand-over per 36), lane q (q = lane & 7 < 6) of each half of a slot computes rotation
+// q, and a sweep is 32 steps instead of 48.  The price is 144 column VGPRs (two waves per SIMD at most) and that
+// the per-column bookkeeping no longer moves with quad permutes: partner entries travel by ds_bpermute, rotation
+// parameters are broadcast with ds_swizzle (lane i of every group of 8) -- 16 LDS-crossbar operations per round,
+// no LDS memory.  Everything else (scaled rotations as two shears, scales folded once per sweep, one barrier per
+// hand-over, analytic column ids) is the quad-block kernel's.
+__device__ __forceinline__ float bperm(int idx4, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(idx4, __float_as_int(v)));
+}
+template <int I> __device__ __forceinline__ float bcast8(float v) {          // lane I of this lane's group of 8
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (I << 5) | 0x18));
+}
+
+// lane (l & 7) = q < 6 of the slot's 16 lanes receives the sum over the 16 lanes of p_q (lanes 6, 7: unspecified)
+__device__ __forceinline__ float reduce_scatter6(const float (&p)[6], bool bit0, bool bit1, bool bit2) {
+  const float k0 = bit0 ? p[1] : p[0], g0 = bit0 ? p[0] : p[1];
+  const float k1 = bit0 ? p[3] : p[2], g1 = bit0 ? p[2] : p[3];
+  const float k2 = bit0 ? p[5] : p[4], g2 = bit0 ? p[4] : p[5];
+  const float u0 = k0 + dppf<qperm(1, 0, 3, 2)>(g0);           // index 0 + bit0
+  const float u1 = k1 + dppf<qperm(1, 0, 3, 2)>(g1);           // index 2 + bit0
+  const float u2 = k2 + dppf<qperm(1, 0, 3, 2)>(g2);           // index 4 + bit0
+  const float ka = bit1 ? u1 : u0, ga = bit1 ? u0 : u1;
+  const float kb = bit1 ? 0.f : u2, gb = bit1 ? u2 : 0.f;
+  float v0 = ka + dppf<qperm(2, 3, 0, 1)>(ga);                 // index (l & 3), sum over the quad
+  float v1 = kb + dppf<qperm(2, 3, 0, 1)>(gb);                 // index 4 + (l & 3) (only 4, 5 exist)
+  // all four quads receive the sum over the quads of both (row_ror:8 first: bitwise identical replicas, see
+  // reduce_scatter4), then each lane keeps the one its (l & 7) names
+  v0 += dppf<0x128>(v0);
+  v1 += dppf<0x128>(v1);
+  v0 += dppf<0x124>(v0);
+  v1 += dppf<0x124>(v1);
+  return bit2 ? v1 : v0;
+}
+
+template <int MAXCH>
+__device__ __forceinline__ void dot6_cols(const v4f (&A0)[MAXCH], const v4f (&B0)[MAXCH], const v4f (&A1)[MAXCH],
+                                          const v4f (&B1)[MAXCH], const v4f (&A2)[MAXCH], const v4f (&B2)[MAXCH],
+                                          const v4f (&A3)[MAXCH], const v4f (&B3)[MAXCH], const v4f (&A4)[MAXCH],
+                                          const v4f (&B4)[MAXCH], const v4f (&A5)[MAXCH], const v4f (&B5)[MAXCH],
+                                          float (&p)[6]) {
+  v2f_rot a0, a1, a2, a3, a4, a5;
+#define BASD_D6_MUL(acc, A, B) asm("v_pk_mul_f32 %0, %1, %2" : "=v"(acc) : "v"(BASD_LO2(A[0])), "v"(BASD_LO2(B[0])))
+#define BASD_D6_FMA(acc, a, b) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+  BASD_D6_MUL(a0, A0, B0); BASD_D6_MUL(a1, A1, B1); BASD_D6_MUL(a2, A2, B2);
+  BASD_D6_MUL(a3, A3, B3); BASD_D6_MUL(a4, A4, B4); BASD_D6_MUL(a5, A5, B5);
+  BASD_D6_FMA(a0, BASD_HI2(A0[0]), BASD_HI2(B0[0])); BASD_D6_FMA(a1, BASD_HI2(A1[0]), BASD_HI2(B1[0]));
+  BASD_D6_FMA(a2, BASD_HI2(A2[0]), BASD_HI2(B2[0])); BASD_D6_FMA(a3, BASD_HI2(A3[0]), BASD_HI2(B3[0]));
+  BASD_D6_FMA(a4, BASD_HI2(A4[0]), BASD_HI2(B4[0])); BASD_D6_FMA(a5, BASD_HI2(A5[0]), BASD_HI2(B5[0]));
+#pragma unroll
+  for (int ch = 1; ch < MAXCH; ++ch) {
+    BASD_D6_FMA(a0, BASD_LO2(A0[ch]), BASD_LO2(B0[ch])); BASD_D6_FMA(a1, BASD_LO2(A1[ch]), BASD_LO2(B1[ch]));
+    BASD_D6_FMA(a2, BASD_LO2(A2[ch]), BASD_LO2(B2[ch])); BASD_D6_FMA(a3, BASD_LO2(A3[ch]), BASD_LO2(B3[ch]));
+    BASD_D6_FMA(a4, BASD_LO2(A4[ch]), BASD_LO2(B4[ch])); BASD_D6_FMA(a5, BASD_LO2(A5[ch]), BASD_LO2(B5[ch]));
+    BASD_D6_FMA(a0, BASD_HI2(A0[ch]), BASD_HI2(B0[ch])); BASD_D6_FMA(a1, BASD_HI2(A1[ch]), BASD_HI2(B1[ch]));
+    BASD_D6_FMA(a2, BASD_HI2(A2[ch]), BASD_HI2(B2[ch])); BASD_D6_FMA(a3, BASD_HI2(A3[ch]), BASD_HI2(B3[ch]));
+    BASD_D6_FMA(a4, BASD_HI2(A4[ch]), BASD_HI2(B4[ch])); BASD_D6_FMA(a5, BASD_HI2(A5[ch]), BASD_HI2(B5[ch]));
+  }
+#undef BASD_D6_MUL
+#undef BASD_D6_FMA
+  p[0] = a0.x + a0.y; p[1] = a1.x + a1.y; p[2] = a2.x + a2.y;
+  p[3] = a3.x + a3.y; p[4] = a4.x + a4.y; p[5] = a5.x + a5.y;
+}
+
+// One round = six independent rotations (X_i, Y_i), column indices 0..11 (0-5 block P, 6-11 block Q) covering all
+// twelve columns of the slot; lane i (of each group of 8) computes rotation i.  The tables are 3 bits per lane:
+// which lane of the group owns the entry a lane needs (gather) or produced the entry a lane owns (scatter).
+template <int X0, int Y0, int X1, int Y1, int X2, int Y2, int X3, int Y3, int X4, int Y4, int X5, int Y5>
+struct Round6 {
+  __host__ __device__ static constexpr int X(int i) {
+    return i == 0 ? X0 : (i == 1 ? X1 : (i == 2 ? X2 : (i == 3 ? X3 : (i == 4 ? X4 : X5))));
+  }
+  __host__ __device__ static constexpr int Y(int i) {
+    return i == 0 ? Y0 : (i == 1 ? Y1 : (i == 2 ? Y2 : (i == 3 ? Y3 : (i == 4 ? Y4 : Y5))));
+  }
+  static constexpr int src_of(int col) {
+    for (int i = 0; i < 6; ++i) if (X(i) == col || Y(i) == col) return i;
+    return 0;
+  }
+  static constexpr bool from_y(int col) {
+    for (int i = 0; i < 6; ++i) if (Y(i) == col) return true;
+    return false;
+  }
+  static constexpr unsigned IDENT = 0 | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12) | (5u << 15) | (6u << 18) | (7u << 21);
+  static constexpr unsigned tail = (6u << 18) | (7u << 21);    // lanes 6, 7 of a group point at themselves
+  static constexpr unsigned gx_tbl() { unsigned t = tail; for (int i = 0; i < 6; ++i) t |= (unsigned)(X(i) % 6) << (3 * i); return t; }
+  static constexpr unsigned gy_tbl() { unsigned t = tail; for (int i = 0; i < 6; ++i) t |= (unsigned)(Y(i) % 6) << (3 * i); return t; }
+  static constexpr unsigned xq_msk() { unsigned t = 0; for (int i = 0; i < 6; ++i) t |= (unsigned)(X(i) / 6) << i; return t; }
+  static constexpr unsigned yq_msk() { unsigned t = 0; for (int i = 0; i < 6; ++i) t |= (unsigned)(Y(i) / 6) << i; return t; }
+  static constexpr unsigned sp_tbl() { unsigned t = tail; for (int j = 0; j < 6; ++j) t |= (unsigned)src_of(j) << (3 * j); return t; }
+  static constexpr unsigned sq_tbl() { unsigned t = tail; for (int j = 0; j < 6; ++j) t |= (unsigned)src_of(6 + j) << (3 * j); return t; }
+  static constexpr unsigned py_msk() { unsigned t = 0; for (int j = 0; j < 6; ++j) t |= (from_y(j) ? 1u : 0u) << j; return t; }
+  static constexpr unsigned qy_msk() { unsigned t = 0; for (int j = 0; j < 6; ++j) t |= (from_y(6 + j) ? 1u : 0u) << j; return t; }
+  static constexpr unsigned gx = gx_tbl(), gy = gy_tbl(), xq = xq_msk(), yq = yq_msk();
+  static constexpr unsigned sp = sp_tbl(), sq = sq_tbl(), py = py_msk(), qy = qy_msk();
+};
+// entry of the lane the table names: register mp where the mask bit of this lane is 0, mq where it is 1
+template <unsigned TBL, unsigned MASK, unsigned IDENT>
+__device__ __forceinline__ float meta_move6(float mp, float mq, int q8, int idx4) {
+  if constexpr (TBL == IDENT) {
+    if constexpr (MASK == 0) return mp;
+    else if constexpr (MASK == 0x3F) return mq;
+    else return ((MASK >> q8) & 1) ? mq : mp;
+  } else {
+    if constexpr (MASK == 0) return bperm(idx4, mp);
+    else if constexpr (MASK == 0x3F) return bperm(idx4, mq);
+    else {
+      const float a = bperm(idx4, mp), b = bperm(idx4, mq);
+      return ((MASK >> q8) & 1) ? b : a;
+    }
+  }
+}
+
+// OCC = waves per SIMD the register allocation aims at: 1 (a batch that leaves every CU at most one matrix at a time:
+// no spills, the latency of the parameter stream is all that counts) or 2 (two matrices per CU hide each other's
+// parameter stream)
+template <int MAXCH, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void jacobi_b6_kernel(
+    float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
+    float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status,
+    const int32_t* __restrict__ active, int active_mode) {
+  // active_mode as in jacobi_b4_kernel
+  extern __shared__ __align__(16) float lds[];
+  const int mat = blockIdx.x;
+  int n_act = n;
+  if (active_mode != 0) {
+    const int av = active[mat];
+    if (av < 0) {
+      if (sweeps_out && threadIdx.x == 0) sweeps_out[mat] = 0;
+      return;
+    }
+    if (active_mode != 3) n_act = av < 2 ? 2 : (av > n ? n : av);
+  }
+  constexpr int LANES = 16;
+  constexpr int CHR = 4 * LANES;
+  constexpr int LDC = CHR * MAXCH;
+  constexpr int LDB = 6 * LDC;
+  const int tid = threadIdx.x;
+  const int k = tid / LANES, sub = tid % LANES, roff = sub * 4, q8 = sub & 7;
+  const bool bit0 = (sub & 1) != 0, bit1 = (sub & 2) != 0, bit2 = (sub & 4) != 0;
+  const bool rlane = q8 < 6;                       // this lane computes a rotation / owns a column entry
+  const int grp4 = ((tid & 63) & ~7) << 2;         // byte index of lane 0 of this lane's group of 8 (ds_bpermute)
+  const int nb_all = (n + 5) / 6;
+  const int S_all = (nb_all + 1) >> 1;
+  const int nb = (n_act + 5) / 6;
+  const int nbe = nb + (nb & 1);
+  const int S = nbe >> 1;
+  float* mbox = lds;                               // [S_all + 1][LDB]
+  float* s_sig = mbox + (size_t)(S_all + 1) * LDB; // [12 S_all] by position
+  int* s_rank = reinterpret_cast<int*>(s_sig + 200);
+  float* s_nrm = reinterpret_cast<float*>(s_rank + 200);  // [S_all + 1][6]
+  float* s_scl = s_nrm + 104;
+  int* s_flag = reinterpret_cast<int*>(s_scl + 104);
+
+  float* src = wg + (size_t)mat * n * ld;
+  int mr = (m + 3) & ~3;
+  if (active_mode == 2) { const int ma = (n_act + 3) & ~3; mr = ma < mr ? ma : mr; }
+  const bool live = k < S;
+  const bool last = k == S - 1;
+  float* const mybox = mbox + (size_t)k * LDB + roff;
+  float* const mymeta = s_nrm + 6 * k + (rlane ? q8 : 5);
+  v4f C[12][MAXCH];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const int idc = 12 * k + c;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      const int r = roff + CHR * ch;
+      C[c][ch] = (live && idc < n_act && r < mr) ? *reinterpret_cast<const v4f*>(src + (size_t)idc * ld + r)
+                                                 : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float nP = 0.f, nQ = 0.f, dP = 1.f, dQ = 1.f;
+  if (tid < 8) s_flag[tid] = 0;
+  __syncthreads();
+
+  const float inv_tol = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / tol)));
+  bool rotated = false, bigrot = false;
+
+  auto round = [&](auto map, bool ok) {
+    using M = decltype(map);
+    // partner entries first: the crossbar latency hides under the dot products
+    const int ixx = grp4 | (((M::gx >> (3 * q8)) & 7) << 2), ixy = grp4 | (((M::gy >> (3 * q8)) & 7) << 2);
+    const float al = meta_move6<M::gx, M::xq, M::IDENT>(nP, nQ, q8, ixx), be = meta_move6<M::gy, M::yq, M::IDENT>(nP, nQ, q8, ixy);
+    const float dx = meta_move6<M::gx, M::xq, M::IDENT>(dP, dQ, q8, ixx), dy = meta_move6<M::gy, M::yq, M::IDENT>(dP, dQ, q8, ixy);
+    float p[6];
+    dot6_cols<MAXCH>(C[M::X(0)], C[M::Y(0)], C[M::X(1)], C[M::Y(1)], C[M::X(2)], C[M::Y(2)], C[M::X(3)], C[M::Y(3)],
+                     C[M::X(4)], C[M::Y(4)], C[M::X(5)], C[M::Y(5)], p);
+    const float gt = reduce_scatter6(p, bit0, bit1, bit2);
+    const float g = gt * dx * dy;
+    const float gsc = g * inv_tol;
+    const float ab_ = al * be;
+    const bool rot = ok & rlane & (gsc * gsc > fmaxf(ab_, BASD_JACOBI_TINY));
+    rotated |= rot;
+    const float gq = g * (1.0f / BASD_JACOBI_QUAD);
+    const bool big_cos = gq * gq > ab_;
+    const float z = (be - al) * __builtin_amdgcn_rcpf(2.f * g);
+    float t = copysignf(1.f, z) * __builtin_amdgcn_rcpf(fabsf(z) + __builtin_amdgcn_sqrtf(fmaf(z, z, 1.f)));
+    t = rot ? t : 0.f;
+    bigrot |= rot & (big_cos | (fabsf(t) > BASD_JACOBI_QUAD_TAN));
+    const float w = fmaf(t, t, 1.f);
+    float c = __builtin_amdgcn_rsqf(w);
+    c = c * fmaf(-0.5f * w, c * c, 1.5f);
+    const float sn = c * t;
+    const float u = sn * __builtin_amdgcn_rcpf(1.0f + c);
+    const float h = sn * u, hp = t * u;
+    const float aln = fmaf(-t, g, al), ben = fmaf(t, g, be);
+    const float a = t * (dy * __builtin_amdgcn_rcpf(dx));
+    const float b = (sn * c) * (dx * __builtin_amdgcn_rcpf(dy));
+    const float dxn = fmaf(-dx, h, dx), dyn = fmaf(dy, hp, dy);
+    v2f_rot ab[6];
+    ab[0] = (v2f_rot){bcast8<0>(a), bcast8<0>(b)};
+    ab[1] = (v2f_rot){bcast8<1>(a), bcast8<1>(b)};
+    ab[2] = (v2f_rot){bcast8<2>(a), bcast8<2>(b)};
+    ab[3] = (v2f_rot){bcast8<3>(a), bcast8<3>(b)};
+    ab[4] = (v2f_rot){bcast8<4>(a), bcast8<4>(b)};
+    ab[5] = (v2f_rot){bcast8<5>(a), bcast8<5>(b)};
+    const int isp = grp4 | (((M::sp >> (3 * q8)) & 7) << 2), isq = grp4 | (((M::sq >> (3 * q8)) & 7) << 2);
+    nP = meta_move6<M::sp, M::py, M::IDENT>(aln, ben, q8, isp);
+    nQ = meta_move6<M::sq, M::qy, M::IDENT>(aln, ben, q8, isq);
+    dP = meta_move6<M::sp, M::py, M::IDENT>(dxn, dyn, q8, isp);
+    dQ = meta_move6<M::sq, M::qy, M::IDENT>(dxn, dyn, q8, isq);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) shear_in_place(C[M::X(i)][ch], C[M::Y(i)][ch], ab[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto fold = [&](bool killP, bool killQ) {
+    const float fP = killP ? 0.f : dP, fQ = killQ ? 0.f : dQ;
+    float f[12];
+    f[0] = bcast8<0>(fP); f[1] = bcast8<1>(fP); f[2] = bcast8<2>(fP);
+    f[3] = bcast8<3>(fP); f[4] = bcast8<4>(fP); f[5] = bcast8<5>(fP);
+    f[6] = bcast8<0>(fQ); f[7] = bcast8<1>(fQ); f[8] = bcast8<2>(fQ);
+    f[9] = bcast8<3>(fQ); f[10] = bcast8<4>(fQ); f[11] = bcast8<5>(fQ);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) C[c][ch] *= f[c];
+    }
+    dP = 1.f; dQ = 1.f;
+  };
+  auto exact_norms = [&](int rows) {
+    float p[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < MAXCH; ++ch) {
+        const int r = roff + CHR * ch;
+        const v4f x = C[c][ch];
+        const float mx = (r + 0 < rows) ? 1.f : 0.f, my = (r + 1 < rows) ? 1.f : 0.f;
+        const float mz = (r + 2 < rows) ? 1.f : 0.f, mw = (r + 3 < rows) ? 1.f : 0.f;
+        a = fmaf(mx * x.x, x.x, fmaf(my * x.y, x.y, fmaf(mz * x.z, x.z, fmaf(mw * x.w, x.w, a))));
+      }
+      p[c] = a;
+    }
+    const float pp[6] = {p[0], p[1], p[2], p[3], p[4], p[5]}, pq[6] = {p[6], p[7], p[8], p[9], p[10], p[11]};
+    nP = reduce_scatter6(pp, bit0, bit1, bit2);
+    nQ = reduce_scatter6(pq, bit0, bit1, bit2);
+    if (!rlane) { nP = 0.f; nQ = 0.f; }
+  };
+
+  int used_sweeps = 0;
+  bool converged = false;
+  int step = 0;
+#pragma unroll 1
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    rotated = false;
+    bigrot = false;
+    fold(false, false);
+    exact_norms(1 << 30);
+    if (live && rlane) atomicMax(&s_flag[4 + (sweep & 1)], __float_as_int(fmaxf(nP, nQ)));
+    lds_barrier();
+    {
+      const float debris = __int_as_float(s_flag[4 + (sweep & 1)]) * BASD_JACOBI_DEBRIS;
+      const bool zP = rlane & (nP < debris), zQ = rlane & (nQ < debris);
+      if (__builtin_amdgcn_ballot_w64(zP || zQ) != 0) {
+        fold(zP, zQ);
+        if (zP) nP = 0.f;
+        if (zQ) nQ = 0.f;
+      }
+    }
+    // the fifteen pairs inside each block, once per sweep: five rounds of three pairs per block
+    round(Round6<0, 5, 1, 4, 2, 3, 6, 11, 7, 10, 8, 9>{}, live);
+    round(Round6<0, 4, 5, 3, 1, 2, 6, 10, 11, 9, 7, 8>{}, live);
+    round(Round6<0, 3, 4, 2, 5, 1, 6, 9, 10, 8, 11, 7>{}, live);
+    round(Round6<0, 2, 3, 1, 4, 5, 6, 8, 9, 7, 10, 11>{}, live);
+    round(Round6<0, 1, 2, 5, 3, 4, 6, 7, 8, 11, 9, 10>{}, live);
+#pragma unroll 1
+    for (int t = 0; t < nbe; ++t, ++step) {
+      const bool even_view = (step & 1) == 0;
+      const bool pair_ok = live & (even_view | !last);
+      round(Round6<0, 6, 1, 7, 2, 8, 3, 9, 4, 10, 5, 11>{}, pair_ok);
+      round(Round6<0, 7, 1, 8, 2, 9, 3, 10, 4, 11, 5, 6>{}, pair_ok);
+      round(Round6<0, 8, 1, 9, 2, 10, 3, 11, 4, 6, 5, 7>{}, pair_ok);
+      round(Round6<0, 9, 1, 10, 2, 11, 3, 6, 4, 7, 5, 8>{}, pair_ok);
+      round(Round6<0, 10, 1, 11, 2, 6, 3, 7, 4, 8, 5, 9>{}, pair_ok);
+      round(Round6<0, 11, 1, 6, 2, 7, 3, 8, 4, 9, 5, 10>{}, pair_ok);
+      if (even_view) {
+        if (live) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + c * LDC + CHR * ch) = C[6 + c][ch];
+          }
+          if (sub < 6) { mymeta[0] = nQ; mymeta[104] = dQ; }
+          if (last) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+#pragma unroll
+              for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + CHR * ch) = C[c][ch];
+            }
+            if (sub < 6) { mymeta[6] = nP; mymeta[104 + 6] = dP; }
+          }
+        }
+        lds_barrier();
+        if (live) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) C[6 + c][ch] = *reinterpret_cast<const v4f*>(mybox + LDB + c * LDC + CHR * ch);
+          }
+          nQ = mymeta[6]; dQ = mymeta[104 + 6];
+        }
+      } else {
+        if (live && !last) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) *reinterpret_cast<v4f*>(mybox + LDB + c * LDC + CHR * ch) = C[c][ch];
+          }
+          if (sub < 6) { mymeta[6] = nP; mymeta[104 + 6] = dP; }
+        }
+        lds_barrier();
+        if (live) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < MAXCH; ++ch) C[c][ch] = *reinterpret_cast<const v4f*>(mybox + c * LDC + CHR * ch);
+          }
+          nP = mymeta[0]; dP = mymeta[104];
+        }
+      }
+    }
+    used_sweeps = sweep + 1;
+    if (rotated) s_flag[sweep & 1] = 1;
+    if (bigrot) s_flag[2 + (sweep & 1)] = 1;
+    lds_barrier();
+    const int any = s_flag[sweep & 1], anybig = s_flag[2 + (sweep & 1)];
+    if (tid == 0) { s_flag[(sweep + 1) & 1] = 0; s_flag[2 + ((sweep + 1) & 1)] = 0; s_flag[4 + ((sweep + 1) & 1)] = 0; }
+    lds_barrier();
+    if (!any || !anybig) { converged = true; break; }
+  }
+
+  fold(false, false);
+  exact_norms(norm_rows);
+  lds_barrier();
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int k2 = tid2 / LANES, sub2 = tid2 % LANES, roff2 = sub2 * 4;
+  const bool live2 = k2 < S;
+  const bool odd = (used_sweeps & 1) != 0;
+  const int bP = live2 ? (odd ? nbe - 1 - 2 * k2 : 2 * k2) : 2 * k2;
+  const int bQ = live2 ? (odd ? nbe - 2 - 2 * k2 : 2 * k2 + 1) : 2 * k2 + 1;
+  if (k2 < S_all && sub2 < 6) {
+    const int idP = 6 * bP + sub2, idQ = 6 * bQ + sub2;
+    s_sig[12 * k2 + sub2] = idP >= n ? -2.f : ((live2 && idP < n_act) ? sqrtf(nP) : -1.f);
+    s_sig[12 * k2 + 6 + sub2] = idQ >= n ? -2.f : ((live2 && idQ < n_act) ? sqrtf(nQ) : -1.f);
+  }
+  lds_barrier();
+  const int n_tot = 12 * S_all;
+  for (int p = tid2; p < n_tot; p += blockDim.x) {
+    int rank = p;
+    if (sort) {
+      const float mine = s_sig[p];
+      rank = 0;
+      for (int c = 0; c < n_tot; ++c) {
+        const float o = s_sig[c];
+        rank += (o > mine) || (o == mine && c < p);
+      }
+    }
+    s_rank[p] = rank;
+  }
+  lds_barrier();
+  if (k2 < S_all) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const int idc = 6 * (c < 6 ? bP : bQ) + (c % 6);
+      const int d = sort ? s_rank[12 * k2 + c] : idc;
+      const float sg = s_sig[12 * k2 + c];
+      if (idc < n && d < n) {
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+          const int r = roff2 + CHR * ch;
+          if (r < ld) *reinterpret_cast<v4f*>(src + (size_t)d * ld + r) = (live2 && r < mr) ? C[c][ch] : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        if (sub2 == 0) sigma[(size_t)mat * n + d] = sg < 0.f ? 0.f : sg;
+      }
+    }
+  }
+  if (sweeps_out && tid2 == 0) sweeps_out[mat] = converged ? used_sweeps : -used_sweeps;
+  report_status(status, converged, s_sig, n_tot, tid2, blockDim.x, 7, mat);
+}
+
 }  // namespace basd
 
 extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int ld, int norm_rows,
@@ -1266,6 +1677,32 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     const int rows4 = (m_rows + 3) & ~3;
     const bool b4_16 = n_cols <= 196 && rows4 <= 256 && (rows4 <= 192 ? n_cols <= 192 : true);
     const bool b4_32 = n_cols <= 192 && rows4 > 256 && rows4 <= 384;
+    const char* b6env = getenv("BASD_JACOBI_B6");
+    // (from 129 columns: below that the quad-block kernel is four waves or fewer itself and its shorter rounds win --
+    // 48 x 64^2: 0.136 vs 0.210 ms)
+    const bool b6 = !(b6env && b6env[0] == '0') && n_cols > 128 && n_cols <= 192 && rows4 <= 192;
+    if (b4 && b6 && batch >= min_batch) {
+      // hex-block ordering: four waves for 192 columns (BASD_JACOBI_B6=0: the quad-block kernel, A/B timing)
+      const int mode = active == nullptr ? 0 : (mask_only ? 3 : (active_rows ? 2 : 1));
+      const int nb6 = (n_cols + 5) / 6, slots6 = (nb6 + 1) / 2;
+      const int threads6 = ((slots6 * 16 + 63) / 64) * 64;
+      const int chn = (rows4 + 63) / 64;
+      const size_t lds6 = ((size_t)(slots6 + 1) * 6 * 64 * chn + 200 * 2 + 104 * 2 + 8) * 4;
+#define BASD_LAUNCH_B6(MC, OC)                                                                       \
+  do {                                                                                               \
+    allow_full_lds((const void*)jacobi_b6_kernel<MC, OC>);                                           \
+    hipLaunchKernelGGL((jacobi_b6_kernel<MC, OC>), dim3(batch), dim3(threads6), lds6, st, w, batch, m_rows, n_cols, \
+                       ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status, active, mode);   \
+  } while (0)
+      const char* occenv = getenv("BASD_JACOBI_B6_OCC");
+      const bool two = occenv ? occenv[0] == '2' : batch > 256;
+      if (chn == 1) BASD_LAUNCH_B6(1, 2);
+      else if (chn == 2) BASD_LAUNCH_B6(2, 2);
+      else if (two) BASD_LAUNCH_B6(3, 2);
+      else BASD_LAUNCH_B6(3, 1);
+#undef BASD_LAUNCH_B6
+      return check_launch("jacobi_svd (hex-block, scaled rotations)");
+    }
     if (b4 && batch >= min_batch && n_cols >= 8 && (b4_16 || b4_32)) {
       const int mode = active == nullptr ? 0 : (mask_only ? 3 : (active_rows ? 2 : 1));
       const int lanes = b4_32 ? 32 : 16;
