@@ -1243,6 +1243,7 @@ template <int I> __device__ __forceinline__ float bcast8(float v) {          // 
 }
 
 // lane (l & 7) = q < 6 of the slot's 16 lanes receives the sum over the 16 lanes of p_q (lanes 6, 7: unspecified)
+template <int LANES>
 __device__ __forceinline__ float reduce_scatter6(const float (&p)[6], bool bit0, bool bit1, bool bit2) {
   const float k0 = bit0 ? p[1] : p[0], g0 = bit0 ? p[0] : p[1];
   const float k1 = bit0 ? p[3] : p[2], g1 = bit0 ? p[2] : p[3];
@@ -1260,7 +1261,13 @@ __device__ __forceinline__ float reduce_scatter6(const float (&p)[6], bool bit0,
   v1 += dppf<0x128>(v1);
   v0 += dppf<0x124>(v0);
   v1 += dppf<0x124>(v1);
-  return bit2 ? v1 : v0;
+  float v = bit2 ? v1 : v0;
+  if constexpr (LANES == 32) {                                  // the slot's two DPP rows (see reduce_scatter4)
+    typedef unsigned int pl_u32x2 __attribute__((ext_vector_type(2)));
+    const pl_u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  return v;
 }
 
 template <int MAXCH>
@@ -1344,8 +1351,10 @@ __device__ __forceinline__ float meta_move6(float mp, float mq, int q8, int idx4
 // OCC = waves per SIMD the register allocation aims at: 1 (a batch that leaves every CU at most one matrix at a time:
 // no spills, the latency of the parameter stream is all that counts) or 2 (two matrices per CU hide each other's
 // parameter stream)
-template <int MAXCH, int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void jacobi_b6_kernel(
+// LANES = 32: columns of up to 384 rows at the same 144 column VGPRs, eight waves (the block pairs of the D_s = 384
+// eigensolver).
+template <int MAXCH, int OCC, int LANES>
+__global__ __launch_bounds__(16 * LANES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void jacobi_b6_kernel(
     float* __restrict__ wg, int batch, int m, int n, int ld, int norm_rows, float tol, int max_sweeps, int sort,
     float* __restrict__ sigma, int32_t* __restrict__ sweeps_out, int32_t* __restrict__ status,
     const int32_t* __restrict__ active, int active_mode) {
@@ -1361,7 +1370,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
     if (active_mode != 3) n_act = av < 2 ? 2 : (av > n ? n : av);
   }
-  constexpr int LANES = 16;
   constexpr int CHR = 4 * LANES;
   constexpr int LDC = CHR * MAXCH;
   constexpr int LDB = 6 * LDC;
@@ -1416,7 +1424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     float p[6];
     dot6_cols<MAXCH>(C[M::X(0)], C[M::Y(0)], C[M::X(1)], C[M::Y(1)], C[M::X(2)], C[M::Y(2)], C[M::X(3)], C[M::Y(3)],
                      C[M::X(4)], C[M::Y(4)], C[M::X(5)], C[M::Y(5)], p);
-    const float gt = reduce_scatter6(p, bit0, bit1, bit2);
+    const float gt = reduce_scatter6<LANES>(p, bit0, bit1, bit2);
     const float g = gt * dx * dy;
     const float gsc = g * inv_tol;
     const float ab_ = al * be;
@@ -1488,8 +1496,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       p[c] = a;
     }
     const float pp[6] = {p[0], p[1], p[2], p[3], p[4], p[5]}, pq[6] = {p[6], p[7], p[8], p[9], p[10], p[11]};
-    nP = reduce_scatter6(pp, bit0, bit1, bit2);
-    nQ = reduce_scatter6(pq, bit0, bit1, bit2);
+    nP = reduce_scatter6<LANES>(pp, bit0, bit1, bit2);
+    nQ = reduce_scatter6<LANES>(pq, bit0, bit1, bit2);
     if (!rlane) { nP = 0.f; nQ = 0.f; }
   };
 
@@ -1680,26 +1688,31 @@ extern "C" int basd_jacobi_svd(float* w, int batch, int m_rows, int n_cols, int 
     const char* b6env = getenv("BASD_JACOBI_B6");
     // (from 129 columns: below that the quad-block kernel is four waves or fewer itself and its shorter rounds win --
     // 48 x 64^2: 0.136 vs 0.210 ms)
-    const bool b6 = !(b6env && b6env[0] == '0') && n_cols > 128 && n_cols <= 192 && rows4 <= 192;
-    if (b4 && b6 && batch >= min_batch) {
+    const bool b6_on = !(b6env && b6env[0] == '0') && n_cols > 128 && n_cols <= 192;
+    const bool b6_16 = b6_on && rows4 <= 192, b6_32 = b6_on && rows4 > 256 && rows4 <= 384;
+    if (b4 && (b6_16 || b6_32) && batch >= min_batch) {
       // hex-block ordering: four waves for 192 columns (BASD_JACOBI_B6=0: the quad-block kernel, A/B timing)
       const int mode = active == nullptr ? 0 : (mask_only ? 3 : (active_rows ? 2 : 1));
+      const int lanes = b6_32 ? 32 : 16;
       const int nb6 = (n_cols + 5) / 6, slots6 = (nb6 + 1) / 2;
-      const int threads6 = ((slots6 * 16 + 63) / 64) * 64;
-      const int chn = (rows4 + 63) / 64;
-      const size_t lds6 = ((size_t)(slots6 + 1) * 6 * 64 * chn + 200 * 2 + 104 * 2 + 8) * 4;
-#define BASD_LAUNCH_B6(MC, OC)                                                                       \
+      const int threads6 = ((slots6 * lanes + 63) / 64) * 64;
+      const int chn = (rows4 + 4 * lanes - 1) / (4 * lanes);
+      const size_t lds6 = ((size_t)(slots6 + 1) * 6 * 4 * lanes * chn + 200 * 2 + 104 * 2 + 8) * 4;
+      if (lds6 > BASD_JACOBI_LDS_BYTES)
+        return fail(BASD_ERR_SHAPE, "jacobi_svd: %d x %d needs %zu B of LDS", m_rows, n_cols, lds6);
+#define BASD_LAUNCH_B6(MC, OC, LN)                                                                   \
   do {                                                                                               \
-    allow_full_lds((const void*)jacobi_b6_kernel<MC, OC>);                                           \
-    hipLaunchKernelGGL((jacobi_b6_kernel<MC, OC>), dim3(batch), dim3(threads6), lds6, st, w, batch, m_rows, n_cols, \
+    allow_full_lds((const void*)jacobi_b6_kernel<MC, OC, LN>);                                       \
+    hipLaunchKernelGGL((jacobi_b6_kernel<MC, OC, LN>), dim3(batch), dim3(threads6), lds6, st, w, batch, m_rows, n_cols, \
                        ld, norm_rows, tol, max_sweeps, sort, sigma, sweeps, status, active, mode);   \
   } while (0)
       const char* occenv = getenv("BASD_JACOBI_B6_OCC");
       const bool two = occenv ? occenv[0] == '2' : batch > 256;
-      if (chn == 1) BASD_LAUNCH_B6(1, 2);
-      else if (chn == 2) BASD_LAUNCH_B6(2, 2);
-      else if (two) BASD_LAUNCH_B6(3, 2);
-      else BASD_LAUNCH_B6(3, 1);
+      if (lanes == 32) BASD_LAUNCH_B6(3, 2, 32);
+      else if (chn == 1) BASD_LAUNCH_B6(1, 2, 16);
+      else if (chn == 2) BASD_LAUNCH_B6(2, 2, 16);
+      else if (two) BASD_LAUNCH_B6(3, 2, 16);
+      else BASD_LAUNCH_B6(3, 1, 16);
 #undef BASD_LAUNCH_B6
       return check_launch("jacobi_svd (hex-block, scaled rotations)");
     }
