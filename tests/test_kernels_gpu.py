@@ -433,6 +433,23 @@ def test_bgemm_f64_symmetric_mode(nat):
     assert torch.equal(c, c.transpose(1, 2))
 
 
+@pytest.mark.parametrize("batch,n,k,dt", [(9, 196, 768, torch.float32), (3, 192, 320, torch.float64),
+                                          (10, 200, 100, torch.float32), (2, 64, 16, torch.float32),
+                                          (3, 132, 52, torch.float32), (17, 256, 64, torch.float64)])
+def test_bgemm_f64_balanced_gram(nat, batch, n, k, dt):
+    """C = X X^T of ONE device operand (same pointer on both sides) into fp64 dispatches gram_rows_f64_kernel: full
+    off-diagonal tiles, diagonal tiles with the ten sub-tiles dealt over the waves, the n % 64 <= 8 trailing rows on
+    the fp64 VALU -- the Gt = t_w t_w^T of the feature-side Procrustes chain is the (196, 768) case"""
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(batch, n, k, generator=g, dtype=torch.float64).to(dt)
+    xd = x.cuda()
+    c = nat.bgemm_f64(xd, xd, trans_b=True, symmetric=True).cpu()
+    ref = x.double() @ x.double().transpose(1, 2)
+    assert c.dtype == torch.float64
+    assert torch.allclose(c, ref, rtol=0, atol=1e-12 * float(ref.abs().max()) * k ** 0.5)
+    assert torch.equal(c, c.transpose(1, 2))
+
+
 def test_jacobi_active_block_matches_full_run(nat):
     """rank-masked input: sweeping only the leading active block gives the same singular values."""
     g = torch.Generator().manual_seed(5)

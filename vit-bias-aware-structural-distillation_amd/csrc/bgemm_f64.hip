@@ -268,6 +268,210 @@ static void launch_bgemm_fast(const void* a, int64_t sa, int lda, int ta, const 
 #undef BASD_BGF
 }
 
+// ---------------------------------------------------------------------------------------------
+// Symmetric Gram C = X X^T of row-major X [n, K] (round 4): the Gt = t_w t_w^T of the feature-side Procrustes chain
+// (n = 196 tokens, K = 768) was the most expensive fp64 launch of a step (1.5 ms per 1024 matrices, 26 TF/s of useful
+// flops against the 45 the kernel above reaches on full tiles), because of how 196 = 3 x 64 + 4 falls on 64 x 64
+// tiles: a diagonal tile needs 10 of its 16 sub-tiles but runs as long as a full one (the wave that owns the lower
+// left quarter does four MFMAs per k step whatever the others skip), and the fourth tile row -- four valid rows -- costs
+// 1.75 tile times.  Here a matrix is
+//   * nt (nt - 1) / 2 full off-diagonal tiles (as above),
+//   * nt diagonal tiles with the 10 sub-tiles dealt 3 / 3 / 2 / 2 to the waves (0.75 tile times; ONE staged operand,
+//     every fragment read serves as row and as column operand),
+//   * one strip workgroup for the r = n - 64 nt <= 8 trailing rows on the fp64 VALU (the strip rows in LDS as fp64,
+//     one column per lane: ~0.4 tile times instead of 1.75),
+// i.e. 5.6 tile times instead of 7.75.
+template <typename TA, int W>
+__device__ __forceinline__ void gram_diag_tile(const TA* __restrict__ X, int ldx, int m0, int n, int K,
+                                               double* __restrict__ C, int ldc, double* __restrict__ As0, int tid) {
+  // reads RS[0 .. NR), products (RS[MA[i]], RS[MB[i]]) -- see the table in the header comment
+  constexpr int NR = (W == 0 || W == 3) ? 2 : 3;
+  constexpr int NM = (W < 2) ? 3 : 2;
+  constexpr int RS[3] = {W == 0 ? 0 : (W == 1 ? 2 : 3), W == 0 ? 1 : (W == 3 ? 2 : 0), W == 0 ? 0 : (W == 3 ? 0 : 1)};
+  constexpr int MA[3] = {0, W == 0 ? 1 : 0, W == 0 ? 1 : 0};
+  constexpr int MB[3] = {W == 0 ? 0 : 1, W == 0 ? 0 : (W == 3 ? 0 : 2), W == 0 ? 1 : 0};
+  const int lane = tid & 63;
+  f64x4 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  typename Vec4<TA>::type ra = fetch4<TA, 0>(X, ldx, m0, n, 0, K, tid);
+  park4<TA, 0>(ra, As0, tid);
+  __syncthreads();
+  const int nchunk = (K + BK - 1) / BK;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int cur = ch & 1;
+    const bool more = ch + 1 < nchunk;
+    if (more) ra = fetch4<TA, 0>(X, ldx, m0, n, (ch + 1) * BK, K, tid);
+    const double* as = As0 + cur * (BK * BLD);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + (lane >> 4);
+      double f[3];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) f[i] = as[kr * BLD + RS[i] * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < NM; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[MA[i]], f[MB[i]], acc[i], 0, 0, 0);
+    }
+    if (more) park4<TA, 0>(ra, As0 + (cur ^ 1) * (BK * BLD), tid);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < NM; ++i) {
+    const int si = RS[MA[i]], sj = RS[MB[i]];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = m0 + si * 16 + (lane >> 4) + 4 * reg;
+      const int col = m0 + sj * 16 + (lane & 15);
+      C[(size_t)r * ldc + col] = acc[i][reg];
+      if (si != sj) C[(size_t)col * ldc + r] = acc[i][reg];
+    }
+  }
+}
+
+constexpr int GRAM_RMAX = 8;                         // strip rows the VALU path takes
+
+template <typename TA>
+__global__ __launch_bounds__(256) void gram_rows_f64_kernel(const TA* __restrict__ x, int64_t sx, int ldx,
+                                                            double* __restrict__ c, int64_t sc, int ldc, int n, int K,
+                                                            int batch) {
+  extern __shared__ __align__(16) double gsm[];
+  double* As0 = gsm;                                 // [2][BK * BLD]
+  double* Bs0 = gsm + 2 * BK * BLD;                  // [2][BK * BLD] (off-diagonal tiles); the strip: [r][K] from gsm
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = n / BT, rs = n - nt * BT;
+  const int n_off = nt * (nt - 1) / 2;
+  const int items = n_off + nt + (rs ? 1 : 0);
+  const int lin = blockIdx.x;
+  const int mat = (lin / (8 * items)) * 8 + (lin & 7);     // all items of a matrix on one XCD (see tile_of_block)
+  if (mat >= batch) return;
+  const int item = (lin >> 3) % items;
+  const TA* X = x + (size_t)mat * sx;
+  double* C = c + (size_t)mat * sc;
+  if (item < n_off) {
+    // ---- full off-diagonal tile (ti > tj)
+    int ti = 1, e = item;
+    while (e >= ti) { e -= ti; ++ti; }
+    const int m0 = ti * BT, n0 = e * BT;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    typename Vec4<TA>::type ra = fetch4<TA, 0>(X, ldx, m0, n, 0, K, tid);
+    typename Vec4<TA>::type rb = fetch4<TA, 0>(X, ldx, n0, n, 0, K, tid);
+    park4<TA, 0>(ra, As0, tid);
+    park4<TA, 0>(rb, Bs0, tid);
+    __syncthreads();
+    const int nchunk = (K + BK - 1) / BK;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int cur = ch & 1;
+      const bool more = ch + 1 < nchunk;
+      if (more) {
+        ra = fetch4<TA, 0>(X, ldx, m0, n, (ch + 1) * BK, K, tid);
+        rb = fetch4<TA, 0>(X, ldx, n0, n, (ch + 1) * BK, K, tid);
+      }
+      const double* as = As0 + cur * (BK * BLD);
+      const double* bs = Bs0 + cur * (BK * BLD);
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        const int kr = kk * 4 + (lane >> 4);
+        double av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = as[kr * BLD + wm + i * 16 + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = bs[kr * BLD + wn + j * 16 + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        park4<TA, 0>(ra, As0 + (cur ^ 1) * (BK * BLD), tid);
+        park4<TA, 0>(rb, Bs0 + (cur ^ 1) * (BK * BLD), tid);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = m0 + wm + i * 16 + (lane >> 4) + 4 * reg;
+          const int col = n0 + wn + j * 16 + (lane & 15);
+          C[(size_t)r * ldc + col] = acc[i][j][reg];
+          C[(size_t)col * ldc + r] = acc[i][j][reg];
+        }
+    return;
+  }
+  if (item < n_off + nt) {
+    // ---- diagonal tile, 10 sub-tiles dealt 3 / 3 / 2 / 2 (every wave runs the same number of barriers)
+    const int m0 = (item - n_off) * BT;
+    if (wave == 0) gram_diag_tile<TA, 0>(X, ldx, m0, n, K, C, ldc, As0, tid);
+    else if (wave == 1) gram_diag_tile<TA, 1>(X, ldx, m0, n, K, C, ldc, As0, tid);
+    else if (wave == 2) gram_diag_tile<TA, 2>(X, ldx, m0, n, K, C, ldc, As0, tid);
+    else gram_diag_tile<TA, 3>(X, ldx, m0, n, K, C, ldc, As0, tid);
+    return;
+  }
+  // ---- the strip: rows s0 .. n-1 against every row j (one j per lane, 64 per wave, 256 per pass)
+  const int s0 = nt * BT;
+  double* S = gsm;                                   // [rs][K]
+  for (int e = tid * 4; e < rs * K; e += 1024) {     // K % 4 == 0
+    const int q = e / K, k = e - q * K;
+    const typename Vec4<TA>::type v = *reinterpret_cast<const typename Vec4<TA>::type*>(X + (size_t)(s0 + q) * ldx + k);
+    double2* d = reinterpret_cast<double2*>(S + q * K + k);
+    d[0] = make_double2((double)v.x, (double)v.y);
+    d[1] = make_double2((double)v.z, (double)v.w);
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + tid;
+    const bool valid = j < n;
+    const TA* xr = X + (size_t)(valid ? j : 0) * ldx;
+    double acc[GRAM_RMAX];
+#pragma unroll
+    for (int q = 0; q < GRAM_RMAX; ++q) acc[q] = 0.0;
+    typename Vec4<TA>::type nx = *reinterpret_cast<const typename Vec4<TA>::type*>(xr);
+    for (int k = 0; k < K; k += 4) {
+      const typename Vec4<TA>::type v = nx;
+      if (k + 4 < K) nx = *reinterpret_cast<const typename Vec4<TA>::type*>(xr + k + 4);
+      const double v0 = (double)v.x, v1 = (double)v.y, v2 = (double)v.z, v3 = (double)v.w;
+#pragma unroll
+      for (int q = 0; q < GRAM_RMAX; ++q)
+        if (q < rs) {
+          const double2 sa = *reinterpret_cast<const double2*>(S + q * K + k);
+          const double2 sb = *reinterpret_cast<const double2*>(S + q * K + k + 2);
+          acc[q] = fma(v0, sa.x, acc[q]);
+          acc[q] = fma(v1, sa.y, acc[q]);
+          acc[q] = fma(v2, sb.x, acc[q]);
+          acc[q] = fma(v3, sb.y, acc[q]);
+        }
+    }
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < GRAM_RMAX; ++q)
+        if (q < rs) {
+          C[(size_t)(s0 + q) * ldc + j] = acc[q];
+          if (j < s0) C[(size_t)j * ldc + s0 + q] = acc[q];
+        }
+    }
+  }
+}
+
+template <typename TA>
+static void launch_gram_rows(const void* a, int64_t sa, int lda, void* c, int64_t sc, int ldc, int batch, int n, int K,
+                             hipStream_t st) {
+  const int nt = n / BT, rs = n - nt * BT;
+  const int items = nt * (nt - 1) / 2 + nt + (rs ? 1 : 0);
+  size_t lds = (size_t)4 * BK * BLD * sizeof(double);
+  const size_t strip = (size_t)rs * K * sizeof(double);
+  if (strip > lds) lds = strip;
+  dim3 grid((unsigned)(((batch + 7) / 8) * 8 * items));
+  hipLaunchKernelGGL((gram_rows_f64_kernel<TA>), grid, dim3(256), lds, st, (const TA*)a, sa, lda, (double*)c, sc, ldc, n, K,
+                     batch);
+}
+
 template <typename TA, typename TB, typename TC>
 static void launch_bgemm(const void* a, int64_t sa, int lda, int ta, const void* b, int64_t sb, int ldb, int tb,
                          void* c, int64_t sc, int ldc, int batch, int M, int N, int K, int sym, const int32_t* skip,
@@ -302,6 +506,17 @@ extern "C" int basd_bgemm_f64_masked(const void* a, int a_dtype, int64_t a_strid
   const int key = a_dtype * 100 + b_dtype * 10 + c_dtype;
   const bool aligned = M % 4 == 0 && N % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
                        a_stride % 4 == 0 && b_stride % 4 == 0 && ((uintptr_t)a & 31) == 0 && ((uintptr_t)b & 31) == 0;
+  // C = X X^T of one row-major operand into fp64: the balanced Gram kernel (BASD_GRAM_ROWS=0: the generic tiles)
+  if (symmetric && a == b && a_dtype == b_dtype && a_stride == b_stride && lda == ldb && !trans_a && trans_b &&
+      c_dtype == BASD_DTYPE_F64 && aligned && skip == nullptr && M >= 64 && (M % 64) <= GRAM_RMAX &&
+      (size_t)(M % 64) * K * 8 <= 65536) {
+    const char* env = getenv("BASD_GRAM_ROWS");
+    if (!(env && env[0] == '0')) {
+      if (a_dtype == BASD_DTYPE_F32) launch_gram_rows<float>(a, a_stride, lda, c, c_stride, ldc, batch, M, K, st);
+      else launch_gram_rows<double>(a, a_stride, lda, c, c_stride, ldc, batch, M, K, st);
+      return check_launch("bgemm_f64 (symmetric Gram)");
+    }
+  }
 #define BASD_BG(TA, TB, TC)                                                                                          \
   do {                                                                                                               \
     if (aligned) launch_bgemm_fast<TA, TB, TC>(a, a_stride, lda, trans_a, b, b_stride, ldb, trans_b, c, c_stride, ldc, batch, M, N, K, symmetric, skip, st); \

@@ -40,7 +40,8 @@ def _polar_feature_side(ops, s_w: torch.Tensor, t_w: torch.Tensor, tol: float):
     once here and once in the backward.)"""
     gt = ops.bgemm_f64(t_w, t_w, trans_b=True, symmetric=True)          # [B, N, N] fp64
     h = ops.bgemm_f64(gt, s_w)                                          # [B, N, D_s] fp64
-    sigma, m = _polar_core_gram(ops, ops.bgemm_f64(s_w, h, trans_a=True), tol)    # Gram of cross, [B, D_s, D_s]
+    # (a symmetric result of two different operands: lower tiles only, mirrored)
+    sigma, m = _polar_core_gram(ops, ops.bgemm_f64(s_w, h, trans_a=True, symmetric=True), tol)    # Gram of cross, [B, D_s, D_s]
     p = ops.bgemm_f64(m, s_w, trans_b=True)                             # m s_w^T  [B, D_s, N] fp64
     p_s = ops.bgemm_f64(gt, p, trans_b=True, out_dtype=torch.float32)   # G_t P^T = t_w G^T  [B, N, D_s]
     a_t = ops.bgemm_f64(s_w, p, out_dtype=torch.float32)                # s_w P  [B, N, N]
