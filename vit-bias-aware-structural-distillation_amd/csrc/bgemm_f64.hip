@@ -219,8 +219,11 @@ __global__ __launch_bounds__(256) void bgemm_f64_fast_kernel(const TA* __restric
     }
     const double* as = As[cur];
     const double* bs = Bs[cur];
+    // a ragged last chunk (K = 196: four valid k of sixteen) only runs the k steps that hold data
+    const int kk_end = (K - ch * BK + 3) >> 2;
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
+      if (kk >= kk_end) break;
       const int kr = kk * 4 + (lane >> 4);
       double av[2], bv[2];
 #pragma unroll
