@@ -43,7 +43,7 @@
  *                          autograd of relational.py:29-46 (centring, sqrt-weights, traces)
  *   basd_attention_bwd_bf16
  *                          autograd through timm Attention.forward of the student (trainer.py:157)
- *   basd_attention_fwd_bf16, basd_cls_importance_bf16
+ *   basd_attention_fwd_bf16, basd_attention_fwd_qmean_bf16, basd_cls_importance_bf16
  *                          timm Attention.forward of the frozen teacher (teacher.py:118 creates it) and the
  *                          attention capture hook src/models/teacher.py:27-39 + relational.py:22-27
  *   basd_layernorm_fwd_bf16 / _bwd_bf16, basd_add_layernorm_fwd_bf16
@@ -339,6 +339,12 @@ int basd_cls_importance_bf16(const void* qkv, int B, int T, int H, int hd, float
  * log-sum-exp of the scaled logits per query (input of basd_attention_bwd_bf16).  hd == 64, T <= 272. */
 int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int hd, float scale, void* out,
                             float* importance, float* lse, void* stream);
+
+/* The same forward for a teacher WITHOUT a CLS token (reference src/losses/relational.py:25-27: the tap is the
+ * attention map averaged over heads and QUERIES): importance [B, H, T] fp32 receives per head
+ * sum_q softmax(q . k * scale)[q][key] / (H T) -- the tap is the sum over the H axis.  Same shapes as above. */
+int basd_attention_fwd_qmean_bf16(const void* qkv, int B, int T, int H, int hd, float scale, void* out,
+                                  float* importance, void* stream);
 
 /* Fused attention backward of a trained block (the student; reference src/training/trainer.py:157 through timm
  * Attention.forward): qkv [B, T, 3, H, hd] bf16, out / dout [B, T, H * hd] bf16 (forward output and its gradient),

@@ -859,6 +859,28 @@ def test_attention_fwd_matches_sdpa(nat, B, T, H, hd):
         assert torch.allclose(imp, nat.cls_importance(qkv.cuda(), H, hd, scale), rtol=2e-2, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,T,H,hd", [(3, 196, 12, 64), (2, 50, 3, 64), (2, 256, 2, 64), (1, 1, 1, 64), (2, 208, 1, 64),
+                                      (2, 256, 4, 80), (2, 209, 1, 80)])
+def test_attention_fwd_query_mean_tap(nat, B, T, H, hd):
+    """the tap of a teacher WITHOUT a CLS token (reference src/losses/relational.py:25-27: attention map averaged over
+    heads and queries) as a by-product of the fused attention forward, vs the map built in fp64 from the same bf16 qkv"""
+    g = torch.Generator().manual_seed(T * 5 + H + hd)
+    qkv = (torch.randn(B, T, 3 * H * hd, generator=g) * 1.2).to(torch.bfloat16)
+    scale = hd ** -0.5
+    out, imp = nat.attention_fwd(qkv.cuda(), H, hd, scale, want_importance=True, query_mean=True)
+    x = qkv.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).double()
+    q, k, v = x[0], x[1], x[2]
+    p = ((q @ k.transpose(-1, -2)) * scale).softmax(dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B, T, H * hd)
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-2 * float(ref.abs().max()) + 1e-3
+    want = p.mean(dim=(1, 2))
+    assert imp.shape == (B, T) and imp.dtype == torch.float32
+    assert torch.allclose(imp.cpu().double(), want, rtol=2e-5, atol=1e-8)
+    assert torch.allclose(imp.sum(-1).cpu(), torch.ones(B), atol=1e-5)
+    out2, _ = nat.attention_fwd(qkv.cuda(), H, hd, scale)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("m,n", [(192, 192), (100, 100), (60, 50), (40, 10), (96, 21)])
 def test_jacobi_block_ordering_large_batch(nat, m, n):
     """batches >= 512 take the block-ordering kernel (two columns per side and slot): singular values,

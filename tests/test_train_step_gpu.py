@@ -299,6 +299,44 @@ def test_vit_huge_teacher_stays_on_the_hip_path_in_strict_mode():
     assert torch.allclose(imps[0], want, rtol=5e-2, atol=2e-5)
 
 
+def test_cls_less_teacher_stays_on_the_hip_path_in_strict_mode():
+    """a ViT teacher WITHOUT a CLS token (reference src/losses/relational.py:25-27: the importance is the attention map
+    averaged over heads and queries): the tap is a by-product of the fused attention kernel, no library fallback; against
+    the map rebuilt from block 0's own qkv"""
+    import basd_amd.losses._ops as O
+    from basd_amd.models.teacher import TeacherModel, extract_intermediates, probe_model
+    from basd_amd.models.vit import VisionTransformer
+    torch.manual_seed(3)
+    model = VisionTransformer(img_size=224, patch_size=16, num_classes=0, embed_dim=384, depth=3, num_heads=6,
+                              class_token=False).cuda().eval()
+    info = probe_model(model, 224)
+    assert info["has_cls_token"] is False and info["num_tokens"] == 196
+    model = model.to(torch.bfloat16)
+    for m in model.modules():
+        if isinstance(m, torch.nn.LayerNorm):
+            m.float()
+    teacher = TeacherModel(model=model, embed_dim=info["embed_dim"], heads_per_layer=info["heads_per_layer"],
+                           depth=info["depth"], mlp_ratio=info["mlp_ratio"], layer_paths=info["layer_paths"],
+                           attn_subpath=info["attn_subpath"], has_cls_token=False, feature_format=info["feature_format"],
+                           mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5))
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    O.FALLBACKS.clear()
+    O.set_strict(True)
+    try:
+        with torch.no_grad():
+            toks, imps = extract_intermediates(teacher, x)
+    finally:
+        O.set_strict(False)
+    assert not O.FALLBACKS, dict(O.FALLBACKS)
+    assert len(toks) == 3 and toks[0].shape == (2, 196, 384) and imps[2].shape == (2, 196)
+    blk = model.blocks[0]
+    with torch.no_grad():
+        h = model.patch_embed(x.to(torch.bfloat16)) + model.pos_embed
+        qkv = blk.attn.qkv(blk.norm1(h)).reshape(2, 196, 3, 6, 64).permute(2, 0, 3, 1, 4)
+        want = ((qkv[0].float() @ qkv[1].float().transpose(-2, -1)) * 64 ** -0.5).softmax(dim=-1).mean(dim=(1, 2))
+    assert torch.allclose(imps[0], want, rtol=1e-4, atol=1e-7)
+
+
 def _make_preset(student, teacher, batch, img=224, patch=16, extra=()):
     from basd_amd.config import load_config
     from basd_amd.train import SyntheticLoader, build

@@ -28,7 +28,7 @@ EXPORTS = (
     "basd_angle_weights_bwd", "basd_mix_tokens", "basd_procrustes_prep", "basd_mix_grad_dots",
     "basd_sf_adamw_step", "basd_lerp", "basd_transpose_bf16_table", "basd_bgemm_f64", "basd_trinv_f64", "basd_bgemm_f64_masked", "basd_trinv_f64_masked", "basd_pchol_f64_masked", "basd_wgrad_bf16", "basd_wgrad_workspace_bytes", "basd_wgrad_bf16_ws", "basd_gemm_bf16",
     "basd_gemm_bf16_gelu_fwd", "basd_gemm_bf16_gelu_bwd", "basd_gemm_bf16x3_f32", "basd_layernorm_fwd_bf16", "basd_layernorm_bwd_bf16",
-    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_bwd_bf16",
+    "basd_cls_importance_bf16", "basd_add_layernorm_fwd_bf16", "basd_procrustes_bwd_rows", "basd_attention_fwd_bf16", "basd_attention_fwd_qmean_bf16", "basd_attention_bwd_bf16",
 )
 
 
@@ -75,6 +75,7 @@ _SIGNATURES = {
     "basd_procrustes_bwd_rows": (_P, _P, _P, _P, _I64, _I, _I, _P, _I, _P, _P),
     "basd_cls_importance_bf16": (_P, _I, _I, _I, _I, _F, _P, _P),
     "basd_attention_fwd_bf16": (_P, _I, _I, _I, _I, _F, _P, _P, _P, _P),
+    "basd_attention_fwd_qmean_bf16": (_P, _I, _I, _I, _I, _F, _P, _P, _P),
     "basd_attention_bwd_bf16": (_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P),
     "basd_sf_adamw_step": (_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _D, _D, _P),
     "basd_lerp": (_P, _P, _I64, _F, _P),
@@ -874,15 +875,23 @@ def attention_fwd_supported(t: int, hd: int) -> bool:
 
 
 def attention_fwd(qkv: torch.Tensor, heads: int, head_dim: int, scale: float, want_importance: bool = False,
-                  want_lse: bool = False):
-    """qkv [B, T, 3 * heads * head_dim] bf16 -> (out [B, T, heads * head_dim] bf16, importance [B, T-1] fp32 | None)
-    and, with ``want_lse``, additionally the log-sum-exp [B, heads, T] fp32 the backward kernel needs.  No autograd
-    here (the student wraps forward + ``attention_bwd`` in an autograd.Function)."""
+                  want_lse: bool = False, query_mean: bool = False):
+    """qkv [B, T, 3 * heads * head_dim] bf16 -> (out [B, T, heads * head_dim] bf16, importance | None) and, with
+    ``want_lse``, additionally the log-sum-exp [B, heads, T] fp32 the backward kernel needs.  importance: the CLS row of
+    the head-averaged attention map without its first entry, [B, T-1] fp32 -- or, with ``query_mean`` (teachers without a
+    CLS token), that map averaged over the queries, [B, T].  No autograd here (the student wraps forward +
+    ``attention_bwd`` in an autograd.Function)."""
     _need_cuda(qkv)
     assert qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 3 * heads * head_dim
     qkv = qkv.contiguous()
     b, t = qkv.shape[0], qkv.shape[1]
     out = torch.empty(b, t, heads * head_dim, dtype=torch.bfloat16, device=qkv.device)
+    if want_importance and query_mean:
+        assert not want_lse
+        imp = torch.empty(b, heads, t, dtype=torch.float32, device=qkv.device)
+        _check(lib().basd_attention_fwd_qmean_bf16(_ptr(qkv), b, t, heads, head_dim, ctypes.c_float(scale), _ptr(out),
+                                                   _ptr(imp), _stream()), "basd_attention_fwd_qmean_bf16")
+        return out, imp.sum(dim=1)
     imp = torch.empty(b, heads, t - 1, dtype=torch.float32, device=qkv.device) if want_importance else None
     lse = torch.empty(b, heads, t, dtype=torch.float32, device=qkv.device) if want_lse else None
     _check(lib().basd_attention_fwd_bf16(_ptr(qkv), b, t, heads, head_dim, ctypes.c_float(scale), _ptr(out), _ptr(imp),

@@ -43,7 +43,14 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   return (unsigned short)(u >> 16);
 }
 
-template <int NKT, int AT_HD>   // key tiles of 16: T <= 16 * NKT; head dim 64 or 80
+template <int CTRL> __device__ __forceinline__ float at_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// QMEAN: the tap of a teacher WITHOUT a CLS token (reference src/losses/relational.py:25-27: the attention map averaged
+// over heads AND queries): importance[b, h, key] = sum_q P[q][key] / (H T) from the probabilities of the main softmax
+// (fp32 logits, as the torch form of this tap used before), [B, H, T]; the caller sums over h as for the CLS tap.
+template <int NKT, int AT_HD, bool QMEAN = false>   // key tiles of 16: T <= 16 * NKT; head dim 64 or 80
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_kernel(const unsigned short* __restrict__ qkv, int T, int H,
                                                             float scale, unsigned short* __restrict__ out,
                                                             float* __restrict__ importance, float* __restrict__ lse) {
@@ -106,6 +113,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   uint4 qnext[NDS];
   load_q(wave, qnext);
+  float csum[QMEAN ? NKT : 1][4];                    // QMEAN: this lane's query column summed over the wave's tiles
+#pragma unroll
+  for (int kt = 0; kt < (QMEAN ? NKT : 1); ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) csum[kt][r] = 0.f;
   for (int qt = wave; qt < nqt; qt += 4) {
     const int q0 = qt * 16;
     // Q fragments of this tile: query q0 + li, d = 32 ks + 8 g .. + 7 (fetched one tile ahead)
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most four tiles of K fragments in flight
     }
     // ---- the attention tap: CLS query (column 0 of tile 0) with bf16-rounded logits, head-averaged
-    if (importance != nullptr && qt == 0) {
+    if (!QMEAN && importance != nullptr && qt == 0) {
       float lr[NKT][4];                              // transient: dead before the P V product needs registers
       float tmx = -3.0e38f;
 #pragma unroll
@@ -190,6 +202,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
+    if constexpr (QMEAN) {
+      const float qinv = (q0 + li < T) ? inv : 0.f;  // padding queries (zero rows of Q) are not part of the mean
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[kt][r] = fmaf(s[kt][r], qinv, csum[kt][r]);
+    }
     // log-sum-exp of the scaled logits (natural log): what the backward kernel recomputes P from
     if (lse != nullptr && g == 0 && q0 + li < T) lse[((size_t)b * H + h) * T + q0 + li] = fmaf(mx, scale, __logf(sum));
     // ---- O = P V
@@ -237,16 +256,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
   }
+  if constexpr (QMEAN) {
+    // sum over the 16 query lanes of a DPP row, then over the waves through the (now free) output staging tiles
+    float* cw = reinterpret_cast<float*>(Os) + wave * (16 * AT_LD / 2);      // 16 * AT_LD bf16 = 8 AT_LD floats >= KROWS
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = csum[kt][r];
+        v = at_dpp_add<0xB1>(v);                     // quad_perm [1,0,3,2]
+        v = at_dpp_add<0x4E>(v);                     // quad_perm [2,3,0,1]
+        v = at_dpp_add<0x124>(v);                    // row_ror:4
+        v = at_dpp_add<0x128>(v);                    // row_ror:8
+        if (li == 0) cw[16 * kt + 4 * g + r] = v;
+      }
+    __syncthreads();
+    const float* c0 = reinterpret_cast<const float*>(Os);
+    const float norm = 1.f / ((float)H * (float)T);
+    for (int key = tid; key < T; key += 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += c0[w * (16 * AT_LD / 2) + key];
+      importance[((size_t)b * H + h) * T + key] = v * norm;
+    }
+  }
 }
 
-template <int NKT, int HD>
+template <int NKT, int HD, bool QMEAN = false>
 static void launch_attention(const void* qkv, int B, int T, int H, float scale, void* out, float* importance,
                              float* lse, hipStream_t st) {
   constexpr int KROWS = 32 * ((NKT + 1) / 2);
   constexpr int LD = (HD + 31) / 32 * 32 + 8;
   const size_t lds = ((size_t)2 * KROWS * LD + 4 * 16 * LD) * sizeof(unsigned short);
-  allow_full_lds((const void*)attention_fwd_kernel<NKT, HD>);
-  hipLaunchKernelGGL((attention_fwd_kernel<NKT, HD>), dim3(B * H), dim3(256), lds, st, (const unsigned short*)qkv, T, H,
+  static_assert(8 * LD >= KROWS, "the output staging tile of a wave holds its query-mean column sums");
+  allow_full_lds((const void*)attention_fwd_kernel<NKT, HD, QMEAN>);
+  hipLaunchKernelGGL((attention_fwd_kernel<NKT, HD, QMEAN>), dim3(B * H), dim3(256), lds, st, (const unsigned short*)qkv, T, H,
                      scale, (unsigned short*)out, importance, lse);
 }
 
@@ -269,4 +313,23 @@ extern "C" int basd_attention_fwd_bf16(const void* qkv, int B, int T, int H, int
     else launch_attention<17, 80>(qkv, B, T, H, scale, out, importance, lse, st);
   }
   return check_launch("attention_fwd");
+}
+
+extern "C" int basd_attention_fwd_qmean_bf16(const void* qkv, int B, int T, int H, int hd, float scale, void* out,
+                                             float* importance, void* stream) {
+  using namespace basd;
+  if (B <= 0) return BASD_OK;
+  if ((hd != 64 && hd != 80) || T < 1 || T > 272 || H < 1)
+    return fail(BASD_ERR_SHAPE, "attention_fwd_qmean: T=%d H=%d hd=%d unsupported (hd 64 | 80, T <= 272)", T, H, hd);
+  if (importance == nullptr) return fail(BASD_ERR_SHAPE, "attention_fwd_qmean: importance is required");
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 64) {
+    if (T <= 64) launch_attention<4, 64, true>(qkv, B, T, H, scale, out, importance, nullptr, st);
+    else if (T <= 208) launch_attention<13, 64, true>(qkv, B, T, H, scale, out, importance, nullptr, st);
+    else launch_attention<17, 64, true>(qkv, B, T, H, scale, out, importance, nullptr, st);
+  } else {
+    if (T <= 208) launch_attention<13, 80, true>(qkv, B, T, H, scale, out, importance, nullptr, st);
+    else launch_attention<17, 80, true>(qkv, B, T, H, scale, out, importance, nullptr, st);
+  }
+  return check_launch("attention_fwd_qmean");
 }

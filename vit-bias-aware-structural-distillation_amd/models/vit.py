@@ -232,8 +232,12 @@ class Attention(nn.Module):
                 and get_ops().handles(qkv_flat) and get_ops().attention_fwd_supported(t, self.head_dim)):
             # frozen block: fused attention straight from the packed projection, the tap as a by-product
             # (csrc/attention.hip)
-            want = self.tap is not None and bool(self.tap["has_cls"]) and t >= 2
-            out_flat, imp = get_ops().attention_fwd(qkv_flat, self.num_heads, self.head_dim, self.scale, want)
+            # the tap: CLS row of the head-averaged map, or (teachers without a CLS token) that map averaged over the
+            # queries -- both by-products of the same kernel
+            has_cls = self.tap is not None and bool(self.tap["has_cls"])
+            want = self.tap is not None and (t >= 2 or not has_cls)
+            out_flat, imp = get_ops().attention_fwd(qkv_flat, self.num_heads, self.head_dim, self.scale, want,
+                                                    query_mean=want and not has_cls)
             if self.tap is not None:
                 if want:
                     self.tap["out"] = imp
