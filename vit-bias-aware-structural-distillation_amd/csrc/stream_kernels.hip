@@ -6,6 +6,7 @@
 //   procrustes_prep   resample + importance normalise + weighted centring + sqrt-weighting
 //                     (src/losses/relational.py:29-46, src/losses/combined.py:9-14)
 // Loads are 16 B per lane (8 bf16 / 4 fp32), grid-stride, <= 2048 workgroups.
+#include <stdlib.h>
 #include "basd_common.h"
 
 namespace basd {
@@ -284,6 +285,138 @@ __global__ __launch_bounds__(1024) void procrustes_prep_v4_kernel(
   }
 }
 
+// Single-pass version (round 4; D_s and D_t multiples of 64, N_s <= 32 TPT): the kernel above reads every token twice
+// (weighted column means, then centring) -- 540 MB per launch at c2 for 366 algorithmic, 0.30 of the HBM roof.  The means
+// are per COLUMN, so a slice of 64 columns can be finished on its own: the 1024 threads of a sample are two sub-blocks
+// of 16 column quads x 32 token groups; a sub-block loads its slice ONCE into registers (TPT quads per thread), combines
+// the weighted partial sums of the 32 token groups through LDS in a fixed order, centres / weights / stores from the
+// registers, and moves on to the slice two further (7 quads per thread: 13 per thread with four
+// sub-blocks of 16 token groups spilled 43 registers at the 128 a 1024-thread workgroup has).  Traces are accumulated per thread as before (fp64 across slices).
+template <typename TS, int TPT>
+__global__ __launch_bounds__(1024) void procrustes_prep_v5_kernel(
+    const TS* __restrict__ s_all, const float* __restrict__ t_all, const float* __restrict__ imp_all,
+    int N_s, int N_t, int D_s, int D_t, int64_t s_batch_stride, float* __restrict__ sw_all,
+    float* __restrict__ tw_all, float* __restrict__ a_all, float* __restrict__ tr_all) {
+  extern __shared__ __align__(16) float sm[];
+  const int n4 = (N_s + 3) & ~3;
+  float* s_a = sm;                                   // [N_s] normalised importance
+  float* s_ra = s_a + n4;                            // [N_s] its square root
+  int* s_lo = reinterpret_cast<int*>(s_ra + n4);     // [N_s]
+  float* s_fr = reinterpret_cast<float*>(s_lo + n4); // [N_s]
+  float* s_part = s_fr + n4;                         // [2 sub-blocks][32 token groups][64] partial weighted sums
+  float* s_mu = s_part + 2 * 32 * 64;                // [2][64]
+  float* s_red = s_mu + 2 * 64;                      // [64]
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const TS* s = s_all + (size_t)b * s_batch_stride;
+  const float* t = t_all + (size_t)b * N_t * D_t;
+  const float* imp = imp_all + (size_t)b * N_t;
+  float* sw = sw_all + (size_t)b * N_s * D_s;
+  float* tw = tw_all + (size_t)b * N_s * D_t;
+  const bool same_n = (N_t == N_s);
+
+  const float ratio = (float)N_t / (float)N_s;
+  float part = 0.f;
+  for (int n = tid; n < N_s; n += nt) {
+    float pos = ((float)n + 0.5f) * ratio - 0.5f;
+    pos = pos < 0.f ? 0.f : pos;
+    int lo = (int)pos;
+    if (lo > N_t - 1) lo = N_t - 1;
+    const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+    const float fr = same_n ? 0.f : pos - (float)lo;
+    const float v = same_n ? imp[n] : imp[lo] * (1.f - fr) + imp[hi] * fr;
+    s_a[n] = v; s_lo[n] = lo; s_fr[n] = fr;
+    part += v;
+  }
+  part = wave_sum(part);
+  if ((tid & 63) == 0) s_red[tid >> 6] = part;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < (nt >> 6); ++w) tot += s_red[w];
+  __syncthreads();
+  for (int n = tid; n < N_s; n += nt) {
+    const float an = s_a[n] / tot;
+    s_a[n] = an;
+    s_ra[n] = sqrtf(an);
+    a_all[(size_t)b * N_s + n] = an;
+  }
+  __syncthreads();
+  const int sb = tid >> 9, tg = (tid >> 4) & 31, cq = tid & 15;
+  const int G_s = D_s >> 6, G = G_s + (D_t >> 6);
+  float* my_part = s_part + ((sb * 32 + tg) * 64 + 4 * cq);
+  double trs = 0.0, trt = 0.0;
+  for (int g0 = 0; g0 < G; g0 += 2) {
+    const int g = g0 + sb;
+    const bool act = g < G, is_s = g < G_s;
+    const int col = is_s ? 64 * g + 4 * cq : 64 * (g - G_s) + 4 * cq;
+    float4 x[TPT];
+    if (act) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < TPT; ++i) {
+        const int n = tg + 32 * i;
+        x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N_s) {
+          if (is_s) {
+            x[i] = load_quad<TS>(s + (size_t)n * D_s + col);
+          } else {
+            const int lo = s_lo[n];
+            float4 v = *reinterpret_cast<const float4*>(t + (size_t)lo * D_t + col);
+            const float fr = s_fr[n];
+            if (fr != 0.f) {
+              const int hi = lo + 1 < N_t ? lo + 1 : N_t - 1;
+              const float4 y = *reinterpret_cast<const float4*>(t + (size_t)hi * D_t + col);
+              v.x = v.x * (1.f - fr) + y.x * fr; v.y = v.y * (1.f - fr) + y.y * fr;
+              v.z = v.z * (1.f - fr) + y.z * fr; v.w = v.w * (1.f - fr) + y.w * fr;
+            }
+            x[i] = v;
+          }
+          const float an = s_a[n];
+          acc.x = fmaf(an, x[i].x, acc.x); acc.y = fmaf(an, x[i].y, acc.y);
+          acc.z = fmaf(an, x[i].z, acc.z); acc.w = fmaf(an, x[i].w, acc.w);
+        }
+      }
+      *reinterpret_cast<float4*>(my_part) = acc;
+    }
+    __syncthreads();
+    if (act && tg == 0) {                            // the 32 token groups in a fixed order
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int k = 0; k < 32; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(s_part + ((sb * 32 + k) * 64 + 4 * cq));
+        m.x += p.x; m.y += p.y; m.z += p.z; m.w += p.w;
+      }
+      *reinterpret_cast<float4*>(s_mu + sb * 64 + 4 * cq) = m;
+    }
+    __syncthreads();
+    if (act) {
+      const float4 mu = *reinterpret_cast<const float4*>(s_mu + sb * 64 + 4 * cq);
+      float* dst = is_s ? sw : tw;
+      const int D = is_s ? D_s : D_t;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < TPT; ++i) {
+        const int n = tg + 32 * i;
+        if (n < N_s) {
+          const float ra = s_ra[n];
+          const float4 v = make_float4(ra * (x[i].x - mu.x), ra * (x[i].y - mu.y), ra * (x[i].z - mu.z), ra * (x[i].w - mu.w));
+          *reinterpret_cast<float4*>(dst + (size_t)n * D + col) = v;
+          acc = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, acc))));
+        }
+      }
+      if (is_s) trs += (double)acc; else trt += (double)acc;      // short fp32 runs, fp64 across them
+    }
+  }
+  trs = wave_sum_d(trs); trt = wave_sum_d(trt);
+  __syncthreads();
+  if ((tid & 63) == 0) { s_red[tid >> 6] = (float)trs; s_red[32 + (tid >> 6)] = (float)trt; }
+  __syncthreads();
+  if (tid == 0) {
+    float x = 0.f, y = 0.f;
+    for (int w = 0; w < (nt >> 6); ++w) { x += s_red[w]; y += s_red[32 + w]; }
+    tr_all[(size_t)b * 2] = x; tr_all[(size_t)b * 2 + 1] = y;
+  }
+}
+
 // Procrustes backward, row epilogue.  p = (other side) G^T comes from a plain GEMM; with R = W - p
 //   out[row, :] = 2 gl sqrt(a[row]) R[row, :]   (the gradient w.r.t. the raw tokens) and
 //   rowdot[row] = 2 gl sum_d R[row, d] W[row, d]  (the part of d loss / d a this side owns)
@@ -550,6 +683,20 @@ extern "C" int basd_procrustes_prep(const void* s, int s_dtype, int64_t s_batch_
   const size_t lds4 = ((size_t)4 * N_s + 4 + 5 * (size_t)(D_s + D_t) + 64) * 4;
   const bool vec_ok = D_s % 4 == 0 && D_t % 4 == 0 && s_batch_stride % 4 == 0 && ((uintptr_t)s & 15) == 0 &&
                       ((uintptr_t)t & 15) == 0 && ((uintptr_t)s_w & 15) == 0 && ((uintptr_t)t_w & 15) == 0 && lds4 <= 64 * 1024;
+  if (vec_ok && (s_dtype == BASD_DTYPE_F32 || s_dtype == BASD_DTYPE_BF16) && D_s % 64 == 0 && D_t % 64 == 0 && N_s <= 256) {
+    // single pass over the tokens (BASD_PREP_V5=0: the two-pass kernel below, A/B timing)
+    const char* env = getenv("BASD_PREP_V5");
+    if (!(env && env[0] == '0')) {
+      const size_t lds5 = ((size_t)4 * ((N_s + 3) & ~3) + 2 * 32 * 64 + 2 * 64 + 64) * 4;
+#define BASD_PREP5(TS, TPT)                                                                                  \
+  hipLaunchKernelGGL((procrustes_prep_v5_kernel<TS, TPT>), dim3(B), dim3(1024), lds5, st, (const TS*)s, t, imp, N_s, N_t, \
+                     D_s, D_t, s_batch_stride, s_w, t_w, a, tr)
+      if (s_dtype == BASD_DTYPE_F32) { if (N_s <= 224) BASD_PREP5(float, 7); else BASD_PREP5(float, 8); }
+      else { if (N_s <= 224) BASD_PREP5(unsigned short, 7); else BASD_PREP5(unsigned short, 8); }
+#undef BASD_PREP5
+      return check_launch("procrustes_prep (single pass)");
+    }
+  }
   if (vec_ok && (s_dtype == BASD_DTYPE_F32 || s_dtype == BASD_DTYPE_BF16)) {
     if (s_dtype == BASD_DTYPE_F32)
       hipLaunchKernelGGL(procrustes_prep_v4_kernel<float>, dim3(B), dim3(1024), lds4, st, (const float*)s, t, imp,
