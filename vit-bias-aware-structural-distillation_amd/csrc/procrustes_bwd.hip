@@ -30,6 +30,7 @@
 // (no change), the whole B strip of a group loaded in one burst into 56 registers (the right idea for the measured
 // bottleneck, but 259 spilled registers at the 168-register budget of three waves per SIMD: 1.78 ms).  Next: a
 // 4-wave / 256-register layout that holds the B strip, or the strip staged through LDS with transposing reads.
+#include <stdlib.h>
 #include "basd_common.h"
 
 namespace basd {
@@ -268,6 +269,246 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   }
 }
 
+typedef short pb_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pb_v4s pb_lds_v4s;
+constexpr int PB_BPITCH = 208;              // bytes between the k rows of the staged W tile (96 bf16 = 192 + 16 pad)
+
+// The same kernel with the B operand (W) staged through LDS -- see the comment at `bload` below.  One operand buffer each
+// (52 KiB with the row dots: two workgroups per CU), two barriers per K step.  Measured (same box, 1024 x [196, 196] x
+// [196, 768]): 1.04 vs 1.15 ms, the c4 shape 0.91 vs 1.01 -- the 4-byte fragment loads were a tenth of the time, not the
+// bulk of it.  What is left is traffic: per matrix W is read twice (operand + residual; 300 MB of W are in flight
+// across the chip, the second read is not an L2 hit), the [n, n] factor once per 96-column group (8 x 154 KB), the
+// gradient written once -- ~3 GB per launch at 3 - 4 TB/s.  Fewer, wider groups (12 waves, one workgroup per CU) would
+// halve the factor's re-reads; keeping it resident needs 154 KiB of bf16 planes.
+template <int MT, typename TO>      // MT = m tiles (16 rows each) >= ceil(n / 16)
+__global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void procrustes_bwd_side_lds_kernel(
+    const float* __restrict__ fac, const float* __restrict__ w, const float* __restrict__ a,
+    const float* __restrict__ gl, int n, int d, TO* __restrict__ out, float* __restrict__ rowdot) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int PLANE = MT * 16 * PB_ROWB;                 // one bf16 plane of one K step
+  constexpr int ITEMS = (MT * 16 * 4 + PB_THREADS - 1) / PB_THREADS;         // staging items (row, k octet) per thread and K step
+  unsigned char* abuf = smem;                              // [2 planes][MT * 16 rows][PB_ROWB]   (ONE buffer)
+  unsigned char* bbuf = smem + 2 * PLANE;                  // [2 planes][32 k rows][PB_BPITCH]: the W tile of a K step
+  float* s_dotw = reinterpret_cast<float*>(smem + 2 * PLANE + 2 * 32 * PB_BPITCH);  // [waves][MT * 16] row dots
+  float* s_c = s_dotw + PB_WAVES * MT * 16;                           // [MT * 16] row scales 2 gl sqrt(a)
+  float* s_park = reinterpret_cast<float*>(abuf);              // [waves][16 rows][16 columns] epilogue tile: the operand
+                                                               // buffers are idle then (80 KiB per workgroup: two per CU)
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* A = fac + (size_t)b * n * n;
+  const float* W = w + (size_t)b * n * d;
+  TO* O = out + (size_t)b * n * d;
+  const int ksteps = (n + 31) >> 5;
+  const int strips = d >> 4;
+  const float c2 = 2.f * gl[b];
+  for (int i = tid; i < MT * 16; i += PB_THREADS) {
+#pragma unroll
+    for (int wv_ = 0; wv_ < PB_WAVES; ++wv_) s_dotw[wv_ * MT * 16 + i] = 0.f;
+    s_c[i] = i < n ? c2 * __builtin_amdgcn_sqrtf(a[(size_t)b * n + i]) : 0.f;
+  }
+
+  // Staging of one K step of A in two halves: the global loads (branch-free: rows / columns beyond n read a clamped,
+  // valid address and are zeroed by a select) are issued BEFORE the MFMAs of the current step, the split into the two
+  // bf16 planes and the LDS writes follow them -- the L2 round trip hides under the matrix work.
+  // n % 4 == 0 and a 16-byte aligned factor (checked by the C entry): every load is 16 bytes wide.  Offsets are
+  // computed once per item = (row, k octet); a K step only adds a uniform base.  Loads that would leave the matrix
+  // (rows >= n of the padded m tiles, the columns >= n of the last K step) are clamped to its last 16 bytes and the
+  // values zeroed by a mask -- applied in the last K step / for the padded rows only.
+  float4 sa[ITEMS][2];
+  unsigned sa_off[ITEMS];
+  const unsigned a_last = (unsigned)n * (unsigned)n - 4u;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int item = tid + PB_THREADS * it;
+    const int row = item >> 2, oct = item & 3;
+    sa_off[it] = (unsigned)(row < n ? row : n - 1) * (unsigned)n + (unsigned)(oct * 8);
+  }
+  auto stage_load = [&](int ks) {
+    const unsigned kbase = (unsigned)ks * 32u;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const unsigned o0 = sa_off[it] + kbase, o1 = o0 + 4u;
+      sa[it][0] = *reinterpret_cast<const float4*>(A + (o0 < a_last ? o0 : a_last));
+      sa[it][1] = *reinterpret_cast<const float4*>(A + (o1 < a_last ? o1 : a_last));
+    }
+  };
+  auto stage_store = [&](int ks, int buf) {
+    unsigned char* dst = abuf;
+    const bool tail = (ks + 1) * 32 > n;                   // uniform
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int item = tid + PB_THREADS * it;
+      const int row = item >> 2, oct = item & 3;
+      if (item < MT * 16 * 4) {
+        float4 v0 = sa[it][0], v1 = sa[it][1];
+        const int k0 = ks * 32 + oct * 8;
+        const float m0 = (row < n && (!tail || k0 + 4 <= n)) ? 1.f : 0.f;
+        const float m1 = (row < n && (!tail || k0 + 8 <= n)) ? 1.f : 0.f;
+        uint4 hi, mid;
+        pb_split2(v0.x * m0, v0.y * m0, hi.x, mid.x); pb_split2(v0.z * m0, v0.w * m0, hi.y, mid.y);
+        pb_split2(v1.x * m1, v1.y * m1, hi.z, mid.z); pb_split2(v1.z * m1, v1.w * m1, hi.w, mid.w);
+        const unsigned lo = (unsigned)row * PB_ROWB + (unsigned)oct * 16;
+        *reinterpret_cast<uint4*>(dst + lo) = hi;
+        *reinterpret_cast<uint4*>(dst + PLANE + lo) = mid;
+      }
+    }
+  };
+
+  for (int g0 = 0; g0 < strips; g0 += PB_WAVES) {          // column groups of PB_WAVES strips (96 columns), one per wave
+    const int s0 = g0 + wave;
+    const bool has = s0 < strips;
+    const int col = (lane & 15);
+    const unsigned cs = has ? (unsigned)(s0 * 16 + col) : (unsigned)col;                // 32-bit offsets: n d < 2^31
+    // The W tile of a K step ([32 k rows][96 columns] fp32, 12 KiB) goes global -> registers (16-byte loads, 384
+    // contiguous bytes per row: two per thread) -> bf16 (hi, mid) planes in LDS, row-major with the k rows PB_BPITCH
+    // bytes apart; a wave's B fragment -- column 16 wave + (lane & 15), rows 8 (lane >> 4) + 0..7 -- comes out of the
+    // transposing read ds_read_b64_tr_b16.  (The version above fetched the fragment with eight 4-byte loads per lane,
+    // 64-byte segments: 2.2 TB/s of such requests was all the 1.08 ms it took.)
+    const int c0 = g0 * 16;                                // first column of the group
+    float4 sb[2];
+    auto bload = [&](int ks) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int item = tid + PB_THREADS * it;            // 768 items = 32 rows x 24 quads
+        const int row = item / 24, q = item - row * 24;
+        const int kr = ks * 32 + row, cc = c0 + 4 * q;
+        const bool ok = kr < n && cc < d;
+        sb[it] = *reinterpret_cast<const float4*>(W + (size_t)(ok ? kr : 0) * d + (ok ? cc : 0));
+        if (!ok) sb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto bstore = [&]() {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int item = tid + PB_THREADS * it;
+        const int row = item / 24, q = item - row * 24;
+        uint2 hi, mid;
+        pb_split2(sb[it].x, sb[it].y, hi.x, mid.x); pb_split2(sb[it].z, sb[it].w, hi.y, mid.y);
+        const unsigned lo = (unsigned)row * PB_BPITCH + (unsigned)q * 8;
+        *reinterpret_cast<uint2*>(bbuf + lo) = hi;
+        *reinterpret_cast<uint2*>(bbuf + 32 * PB_BPITCH + lo) = mid;
+      }
+    };
+    __syncthreads();                                       // previous group's fragment reads are done
+    stage_load(0);
+    bload(0);
+    stage_store(0, 0);
+    bstore();
+    __syncthreads();
+    pb_f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (pb_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const bool more = ks + 1 < ksteps;
+      if (more) {                                          // next step's operands: loads only, stored after the MFMAs
+        bload(ks + 1);
+        stage_load(ks + 1);
+      }
+      pb_bf16x8 bh, bm;
+      {
+        const int li = lane & 15, qq = li >> 2, pp = li & 3;
+        const unsigned char* b0 = bbuf + (size_t)((lane >> 4) * 8 + qq) * PB_BPITCH + (size_t)(wave * 16 + 4 * pp) * 2;
+        const pb_v4s h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pb_lds_v4s*)b0);
+        const pb_v4s h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pb_lds_v4s*)(b0 + 4 * PB_BPITCH));
+        const pb_v4s m0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pb_lds_v4s*)(b0 + 32 * PB_BPITCH));
+        const pb_v4s m1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pb_lds_v4s*)(b0 + 32 * PB_BPITCH + 4 * PB_BPITCH));
+        bh = (pb_bf16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        bm = (pb_bf16x8){m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+      }
+      // A fragments in two batches of (MT + 1) / 2 tiles: all 16-byte fragment reads of a batch are issued together (one
+      // exposed LDS latency per batch; a fence per tile pair exposed it MT / 2 times per K step: 4.8 k cycles per step
+      // measured with in-kernel stamps against 0.6 k of matrix work), the fence between the batches keeps the
+      // scheduler from hoisting the second batch on top of the first (registers)
+      const unsigned char* ap = abuf + (size_t)(lane & 15) * PB_ROWB + (lane >> 4) * 16;
+      constexpr int HB = (MT + 1) / 2;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        pb_bf16x8 fh[HB], fm[HB];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          const int i = hb * HB + j < MT ? hb * HB + j : MT - 1;
+          fh[j] = *reinterpret_cast<const pb_bf16x8*>(ap + (size_t)i * 16 * PB_ROWB);
+          fm[j] = *reinterpret_cast<const pb_bf16x8*>(ap + PLANE + (size_t)i * 16 * PB_ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          const int i = hb * HB + j;
+          if (i < MT) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[j], bh, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[j], bm, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[j], bh, acc[i], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();                                     // every wave has read the operands of step ks
+      if (more) { stage_store(ks + 1, 0); bstore(); }
+      __syncthreads();                                     // step ks + 1 is complete
+    }
+    // ---- epilogue.  acc[i][r] = P at row 16 i + 4 (lane >> 4) + r, column 16 s0 + (lane & 15): one value per lane
+    // and row -- consumed in that layout the residual costs a 4-byte load, a 4-byte store and a 16-lane reduction per
+    // element group (measured: 0.8 of 1.2 ms).  Instead the wave parks one 16 x 16 tile at a time in its own 1 KiB of
+    // LDS and reads it back row-wise: 16 bytes per lane, 64 contiguous bytes per row segment for the W load and the
+    // store, a 4-lane reduction per row.  All W loads of the strip are issued before the first tile is processed.
+    float* park = s_park + wave * 256;
+    const int g4 = lane >> 4;
+    const int prow = lane >> 2, pch = lane & 3;            // row-wise walk: 16 rows x 4 chunks of 4 columns
+    const int pcol = s0 * 16 + pch * 4;
+    constexpr int H0 = (MT + 1) / 2;                       // tiles per batch: the W loads of a batch are in flight together
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      constexpr int HN = H0;
+      float4 wq[HN];
+#pragma unroll
+      for (int j = 0; j < HN; ++j) {
+        const int i = hb * H0 + j;
+        const int row = i * 16 + prow;
+        const bool ok = has && row < n && i < MT;
+        wq[j] = *reinterpret_cast<const float4*>(W + (unsigned)(ok ? row : 0) * (unsigned)d + (unsigned)(ok ? pcol : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < HN; ++j) {
+        const int i = hb * H0 + j;
+        if (i < MT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) park[(g4 * 4 + r) * 16 + col] = acc[i][r];
+          // wave-private tile: the wave's own LDS writes precede its reads (in order), no barrier
+          const float4 pv = *reinterpret_cast<const float4*>(park + prow * 16 + pch * 4);
+          const int row = i * 16 + prow;
+          const bool ok = has && row < n;
+          const unsigned off = (unsigned)(ok ? row : 0) * (unsigned)d + (unsigned)(ok ? pcol : 0);
+          const float4 wv = wq[j];
+          const float cr = s_c[row];
+          const float4 rv = make_float4(wv.x - pv.x, wv.y - pv.y, wv.z - pv.z, wv.w - pv.w);
+          float dot = ok ? fmaf(rv.x, wv.x, fmaf(rv.y, wv.y, fmaf(rv.z, wv.z, rv.w * wv.w))) : 0.f;
+          if (ok) {
+            if constexpr (sizeof(TO) == 4) {
+              *reinterpret_cast<float4*>(O + off) = make_float4(cr * rv.x, cr * rv.y, cr * rv.z, cr * rv.w);
+            } else {
+              uint2 o;
+              o.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(cr * rv.x)) |
+                    ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)(cr * rv.y)) << 16);
+              o.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(cr * rv.z)) |
+                    ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)(cr * rv.w)) << 16);
+              *reinterpret_cast<uint2*>(O + off) = o;
+            }
+          }
+          dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0xB1, 0xF, 0xF, true));     // quad_perm 1,0,3,2
+          dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0x4E, 0xF, 0xF, true));     // quad_perm 2,3,0,1
+          if (pch == 0) s_dotw[wave * (MT * 16) + row] += c2 * dot;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += PB_THREADS) {
+    float t = 0.f;
+#pragma unroll
+    for (int wv_ = 0; wv_ < PB_WAVES; ++wv_) t += s_dotw[wv_ * MT * 16 + i];
+    rowdot[(size_t)b * n + i] = t;
+  }
+}
+
 // g_a = (dot_s + dot_t) / (2 a)
 __global__ __launch_bounds__(256) void procrustes_ga_kernel(const float* __restrict__ dot_s, const float* __restrict__ dot_t,
                                                            const float* __restrict__ a, int64_t total,
@@ -280,12 +521,23 @@ template <typename TO>
 static int launch_side(const float* fac, const float* w, const float* a, const float* gl, int batch, int n, int d,
                        TO* out, float* rowdot, hipStream_t st) {
   const int mt = (n + 15) / 16;
+  // W through LDS (BASD_PBWD_LDSB=0: straight from global memory as in the first version, A/B timing); the parked
+  // epilogue tiles (6 KiB) alias the A buffer: MT >= 4 rows of tiles
+  const char* env = getenv("BASD_PBWD_LDSB");
+  const bool ldsb = !(env && env[0] == '0') && mt >= 4;
 #define BASD_PB_LAUNCH(MT)                                                                                   \
   do {                                                                                                       \
     const size_t lds = (size_t)4 * MT * 16 * PB_ROWB + (size_t)MT * 16 * 4 * (PB_WAVES + 1);       /* MT >= 2: the parked tiles fit */                                  \
-    allow_full_lds((const void*)procrustes_bwd_side_kernel<MT, TO>);                                         \
-    hipLaunchKernelGGL((procrustes_bwd_side_kernel<MT, TO>), dim3(batch), dim3(PB_THREADS), lds, st, fac, w, a, gl, n, d, \
-                       out, rowdot);                                                                         \
+    const size_t lds2 = (size_t)2 * MT * 16 * PB_ROWB + (size_t)2 * 32 * PB_BPITCH + (size_t)MT * 16 * 4 * (PB_WAVES + 1);  \
+    if (ldsb) {                                                                                              \
+      allow_full_lds((const void*)procrustes_bwd_side_lds_kernel<MT, TO>);                                   \
+      hipLaunchKernelGGL((procrustes_bwd_side_lds_kernel<MT, TO>), dim3(batch), dim3(PB_THREADS), lds2, st, fac, w, a, gl, n, \
+                         d, out, rowdot);                                                                    \
+    } else {                                                                                                 \
+      allow_full_lds((const void*)procrustes_bwd_side_kernel<MT, TO>);                                       \
+      hipLaunchKernelGGL((procrustes_bwd_side_kernel<MT, TO>), dim3(batch), dim3(PB_THREADS), lds, st, fac, w, a, gl, n, d, \
+                         out, rowdot);                                                                       \
+    }                                                                                                        \
   } while (0)
   if (mt <= 2) BASD_PB_LAUNCH(2);
   else if (mt <= 4) BASD_PB_LAUNCH(4);
