@@ -29,7 +29,12 @@ def _colmajor(a: torch.Tensor, ld: int) -> torch.Tensor:
     return w.contiguous()
 
 
-@pytest.mark.parametrize("m,n,batch", [(40, 32, 5), (33, 17, 3), (192, 192, 4), (196, 192, 2), (64, 7, 2)])
+@pytest.mark.parametrize("m,n,batch", [(40, 32, 5), (33, 17, 3), (192, 192, 4), (196, 192, 2), (64, 7, 2),
+                                       # the hex-block kernel (129 .. 192 columns, up to 192 rows; 32-lane slots for 257 .. 384
+                                       # rows): ragged last blocks (n % 6, n % 12), a phantom block, one / two / three row chunks,
+                                       # two matrices per CU (batch > 256)
+                                       (192, 130, 3), (150, 150, 2), (176, 191, 2), (64, 180, 2), (120, 133, 300),
+                                       (384, 192, 3), (300, 170, 2)])
 def test_jacobi_singular_values_and_invariants(nat, m, n, batch):
     g = torch.Generator().manual_seed(m * 1000 + n)
     a = torch.randn(batch, m, n, generator=g)
@@ -41,16 +46,25 @@ def test_jacobi_singular_values_and_invariants(nat, m, n, batch):
     sigma, sweeps = nat.jacobi_svd(w, m)
     torch.cuda.synchronize()
     ref = torch.linalg.svdvals(ad)
+    if m < n:
+        ref = torch.cat([ref, torch.zeros(batch, n - m, dtype=ref.dtype)], dim=1)
     sig = sigma.cpu().double()
     # column-graded input: one-sided Jacobi keeps RELATIVE accuracy of every singular value
-    err = float((sig / ref - 1).abs().max())
+    err = float((sig[:, :min(m, n)] / ref[:, :min(m, n)] - 1).abs().max())
     print(f"jacobi {m}x{n}: max rel sigma error {err:.2e}, sweeps {sweeps.tolist()}")
     # relative accuracy is eps * kappa(B) for A = B D; a square Gaussian B (192x192) has kappa ~ 1e3
-    assert err < (2e-5 if m == n else 5e-6)
+    if m < n:                                                 # wide: n - m exact zeros, the rest to relative accuracy
+        assert float(sig[:, m:].abs().max()) < 1e-6 * float(ref.max())
+        err = float((sig[:, :m] / ref[:, :m] - 1).abs().max())
+    assert err < (5e-5 if m <= n else 5e-6)       # square Gaussian B: kappa ~ 1e3 (192 x 192: 1e-5 .. 3e-5 by seed)
     wf = w.cpu().double()[:, :, :m].transpose(1, 2)          # [batch, m, n] = U Sigma
     gram = wf.transpose(1, 2) @ wf
     off = gram - torch.diag_embed(torch.diagonal(gram, dim1=1, dim2=2))
     scale = torch.sqrt(torch.diagonal(gram, dim1=1, dim2=2))
+    if m < n:                                                 # the null columns have no direction
+        live = (scale > 1e-6 * scale.amax(dim=1, keepdim=True)).double()
+        off = off * live.unsqueeze(1) * live.unsqueeze(2)
+        scale = scale.clamp_min(1e-30)
     assert (off / (scale.unsqueeze(1) * scale.unsqueeze(2))).abs().max() < 5e-6
     # right rotations leave A A^T unchanged
     aat = ad @ ad.transpose(1, 2)
@@ -450,10 +464,11 @@ def test_bgemm_f64_balanced_gram(nat, batch, n, k, dt):
     assert torch.equal(c, c.transpose(1, 2))
 
 
-def test_jacobi_active_block_matches_full_run(nat):
-    """rank-masked input: sweeping only the leading active block gives the same singular values."""
+@pytest.mark.parametrize("n,ks", [(64, [5, 17, 40, 64]), (192, [7, 84, 131, 192, 2, 97])])
+def test_jacobi_active_block_matches_full_run(nat, n, ks):
+    """rank-masked input: sweeping only the leading active block gives the same singular values (n = 192: the hex-block
+    kernel's active-columns / active-rows modes, the principal-angle launch of a c2 step)."""
     g = torch.Generator().manual_seed(5)
-    n, ks = 64, [5, 17, 40, 64]
     a = torch.zeros(len(ks), n, n)
     for b, k in enumerate(ks):
         a[b, :k, :k] = torch.randn(k, k, generator=g)
@@ -467,6 +482,16 @@ def test_jacobi_active_block_matches_full_run(nat):
     assert torch.allclose(s1, s2, rtol=2e-5, atol=1e-6)
     for b, k in enumerate(ks):            # columns beyond the block stay exactly zero
         assert float(s2[b, k:].abs().max()) == 0.0 if k < n else True
+    # the mask mode: negative entries skip a matrix altogether (outputs untouched), the others are solved completely
+    w3 = _colmajor(a.cuda(), ld)
+    keep = w3.clone()
+    mask = torch.tensor([(-1 if b % 2 else n) for b in range(len(ks))], dtype=torch.int32, device="cuda")
+    s3, sw3 = nat.jacobi_svd(w3, n, active=mask, active_rows=2)
+    for b in range(len(ks)):
+        if b % 2:
+            assert torch.equal(w3[b], keep[b]) and int(sw3[b]) == 0
+        else:
+            assert torch.allclose(s3[b], s1[b], rtol=2e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("M,N,K,gelu,bias", [(50432, 3072, 768, True, True), (50432, 768, 3072, False, True),
