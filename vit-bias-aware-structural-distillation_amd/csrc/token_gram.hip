@@ -7,6 +7,7 @@
 // Workgroup = 512 threads (8 waves), 64-row tiles, grid-stride; the fp64 Gram
 // accumulators (lower-triangular 16x16 tiles) stay in registers across all the
 // tiles of a workgroup and are added to HBM once (fp64 atomics, <= 256 WGs).
+#include <stdlib.h>
 #include "basd_common.h"
 
 namespace basd {
@@ -389,6 +390,212 @@ __global__ __launch_bounds__(256) void token_gram_bf16x3_kernel(const unsigned s
   if (tid < D_OUT) atomicAdd(&colsum[tid], csum);
 }
 
+// 256-row tiles (round 4).  The projection loop above is bound by the L2 round trip of a P chunk, whatever the number of
+// MFMAs under it, and 50 176 rows are 392 tiles of 128 on 256 workgroups: 136 of them run two tiles, i.e. two times 24
+// round trips.  Here a wave carries FOUR row groups of 16 (tile = 256 rows: 196 workgroups, one tile each, one set of
+// round trips; every B fragment read serves four row groups), and the Gram phase runs twice on 128-row halves of the
+// tile (the z half tile + its means fit the 106 KiB the P buffers leave; the other half waits in the accumulators).
+// The Gram accumulators only live from the first Gram pass to the end of the tile (flushed with the fp64 atomics per
+// tile), so the projection has the register file to itself.
+template <int NCT>   // NCT = d_out / 16 (12 for d_out = 192)
+__global__ __launch_bounds__(256) void token_gram_bf16x3_t256_kernel(const unsigned short* __restrict__ x, int64_t rows,
+                                                                int d_in, int rows_per_batch, int64_t batch_stride,
+                                                                const unsigned short* __restrict__ psplit,
+                                                                double* __restrict__ gram,
+                                                                double* __restrict__ colsum) {
+  constexpr int D_OUT = NCT * 16;
+  constexpr int LDZ = D_OUT + 16;
+  constexpr int NGT = NCT * (NCT + 1) / 2;
+  constexpr int GT_PER_WAVE = (NGT + 3) / 4;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* Pl = smem;                                   // [3][D_OUT][PROW] bytes   (projection phase)
+  float* Z = reinterpret_cast<float*>(smem);                  // [TM2][LDZ] floats        (Gram phase)
+  __shared__ unsigned char s_it[NGT], s_jt[NGT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int g = tid; g < NGT; g += 256) {
+    int it = 0;
+    while ((it + 1) * (it + 2) / 2 <= g) ++it;
+    s_it[g] = (unsigned char)it;
+    s_jt[g] = (unsigned char)(g - it * (it + 1) / 2);
+  }
+  double csum = 0.0;
+  const size_t split_stride = (size_t)D_OUT * d_in;
+  __syncthreads();                              // s_it / s_jt
+
+  const int64_t ntiles = (rows + 2 * TM2 - 1) / (2 * TM2);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // row group g of wave w: rows tile * 256 + (g >> 1) * 128 + w * 32 + (g & 1) * 16 + (lane & 15): the groups {0, 1}
+    // of the four waves are the first 128 rows of the tile (Gram pass 0), the groups {2, 3} the second 128
+    f32x4 zacc[4][NCT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) zacc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned short* xr[4];
+    bool rok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t r = tile * (2 * TM2) + (g >> 1) * TM2 + wave * 32 + (g & 1) * 16 + (lane & 15);
+      rok[g] = r < rows;
+      const int64_t rr = rok[g] ? r : 0;
+      const int64_t bq = rr / rows_per_batch;                              // strided [B, N, D] views
+      xr[g] = x + bq * batch_stride + (rr - bq * rows_per_batch) * d_in + 8 * (lane >> 4);
+    }
+    // software pipeline over K chunks: the global loads of chunk c+1 (three P splits -> registers,
+    // A fragments) are issued before the MFMAs of chunk c and land in the OTHER LDS buffer after
+    // them; one barrier per chunk.  (The unpipelined loop spent ~5 us per chunk waiting on L2.)
+    constexpr int PVEC = (3 * D_OUT * 4 + 255) / 256;          // uint4 per thread per chunk
+    // (Measured and rejected: a second register set so that two chunks are in flight -- the loop unrolled by two spills
+    // ~100 scratch operations per chunk pair even with the Gram accumulators out of the way: 393 vs 150 us.)
+    uint4 pre[PVEC];
+    bf16x8 an[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+      for (int v = 0; v < PVEC; ++v) {
+        const int e = tid + 256 * v;
+        const int q = e & 3, rc = e >> 2;
+        const int sp = rc / D_OUT, col = rc - sp * D_OUT;
+        pre[v] = (rc < 3 * D_OUT)
+                     ? *reinterpret_cast<const uint4*>(psplit + sp * split_stride + (size_t)col * d_in + k0 + 8 * q)
+                     : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        an[g] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (rok[g]) an[g] = *reinterpret_cast<const bf16x8*>(xr[g] + k0);
+      }
+    };
+    auto stash = [&](unsigned char* buf) {
+#pragma unroll
+      for (int v = 0; v < PVEC; ++v) {
+        const int e = tid + 256 * v;
+        const int q = e & 3, rc = e >> 2;
+        if (rc < 3 * D_OUT) *reinterpret_cast<uint4*>(buf + (size_t)rc * PROW + 16 * q) = pre[v];
+      }
+    };
+    constexpr size_t PBUF = (size_t)3 * D_OUT * PROW;
+    __syncthreads();                           // the Gram phase of the previous tile no longer reads Z
+    fetch(0);
+    stash(Pl);
+    bf16x8 ac[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ac[g] = an[g];
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < d_in; k0 += KC2) {
+      const bool more = k0 + KC2 < d_in;
+      if (more) fetch(k0 + KC2);
+      const unsigned char* Pc = Pl + cur * PBUF;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(
+              Pc + (size_t)(s_ * D_OUT + c * 16 + (lane & 15)) * PROW + 16 * (lane >> 4));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) zacc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[g], b, zacc[g][c], 0, 0, 0);
+        }
+      }
+      if (more) {
+        stash(Pl + (cur ^ 1) * PBUF);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ac[g] = an[g];
+      }
+      cur ^= 1;
+      __syncthreads();
+    }
+    f64x4 gacc[GT_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < GT_PER_WAVE; ++i) gacc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+    const int64_t rows_left = rows - (tile * (2 * TM2) + pass * TM2);
+    if (rows_left <= 0) break;                 // uniform
+    __syncthreads();                          // all fragment reads (pass 0) / Gram reads of pass 0 (pass 1) are done
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          Z[(wave * 32 + g * 16 + (lane >> 4) * 4 + reg) * LDZ + c * 16 + (lane & 15)] = zacc[2 * pass + g][c][reg];
+    __syncthreads();
+    // ---- Gram of the tile.  With s = the tile's exact column sums (fp64), n its rows and mu ANY fp32 vector,
+    //     sum_rows z z^T = G_c + mu w^T + w mu^T,   G_c = sum (z - mu)(z - mu)^T,   w = s - (n / 2) mu.
+    // mu = the fp32-rounded column mean keeps the entries of z - mu small (and the subtraction exact): G_c runs on the
+    // fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 sums over 128 rows), the two rank-1 terms are
+    // one fp64 MFMA per Gram tile, everything is added up in fp64.  The caller forms the centred Gram as unc - s s^T / m:
+    // with an fp32 Gram of the UNcentred tokens that subtraction cancels the leading digits whenever the token mean
+    // dominates their spread; the all-fp64 Gram before it ran at half the MFMA rate and made this phase (41 k cycles per
+    // tile) longer than the three-split projection (28 k).
+    const int nvalid = rows_left < TM2 ? (int)rows_left : TM2;
+    float* mu = Z + (size_t)TM2 * LDZ;                     // [D_OUT] fp32 tile mean (behind the z tile)
+    double* wv = reinterpret_cast<double*>(mu + D_OUT);    // [D_OUT] fp64 w
+    if (tid < D_OUT) {
+      double sacc = 0.0;
+      for (int r = 0; r < TM2; ++r) sacc += (double)Z[r * LDZ + tid];      // rows beyond `rows` are zeros
+      const float m_ = (float)(sacc / (double)nvalid);
+      mu[tid] = m_;
+      wv[tid] = sacc - 0.5 * (double)nvalid * (double)m_;
+      csum += sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < nvalid * D_OUT; e += 256) {
+      const int r = e / D_OUT, c = e - r * D_OUT;
+      Z[r * LDZ + c] -= mu[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int gi = 0; gi < GT_PER_WAVE; ++gi) {
+      const int g = wave + gi * 4;
+      if (g < NGT) {
+        const int it = s_it[g], jt = s_jt[g];
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int kk = 0; kk < TM2 / 4; ++kk) {
+          const float* zr = Z + (kk * 4 + (lane >> 4)) * LDZ + (lane & 15);
+          t = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[it * 16], zr[jt * 16], t, 0, 0, 0);
+        }
+        // the fp32 tile holds rows 4 q + reg (q = lane >> 4), the fp64 accumulator rows q + 4 reg: a 4 x 4 transpose
+        // between lane group and register -- two register <-> lane butterflies
+        {
+          typedef unsigned int tg_u32x2 __attribute__((ext_vector_type(2)));
+          tg_u32x2 a02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[0]), __float_as_uint(t[2]), false, false);
+          tg_u32x2 a13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[1]), __float_as_uint(t[3]), false, false);
+          tg_u32x2 b01 = __builtin_amdgcn_permlane16_swap(a02[0], a13[0], false, false);
+          tg_u32x2 b23 = __builtin_amdgcn_permlane16_swap(a02[1], a13[1], false, false);
+          gacc[gi][0] += (double)__uint_as_float(b01[0]);
+          gacc[gi][1] += (double)__uint_as_float(b01[1]);
+          gacc[gi][2] += (double)__uint_as_float(b23[0]);
+          gacc[gi][3] += (double)__uint_as_float(b23[1]);
+        }
+        // + mu w^T + w mu^T: k slot 0 carries (mu_i, w_j), k slot 1 (w_i, mu_j), the other two are zero
+        const int ks = lane >> 4;
+        const double mi = (double)mu[it * 16 + (lane & 15)], mj = (double)mu[jt * 16 + (lane & 15)];
+        const double wi = wv[it * 16 + (lane & 15)], wj = wv[jt * 16 + (lane & 15)];
+        const double ai = ks == 0 ? mi : ks == 1 ? wi : 0.0;
+        const double bj = ks == 0 ? wj : ks == 1 ? mj : 0.0;
+        gacc[gi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bj, gacc[gi], 0, 0, 0);
+      }
+    }
+    }   // pass
+#pragma unroll
+    for (int gi = 0; gi < GT_PER_WAVE; ++gi) {
+      const int g = wave + gi * 4;
+      if (g < NGT) {
+        const int it = s_it[g], jt = s_jt[g];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int i = it * 16 + (lane >> 4) + 4 * reg;
+          const int j = jt * 16 + (lane & 15);
+          atomicAdd(&gram[(size_t)i * D_OUT + j], gacc[gi][reg]);
+        }
+      }
+    }
+  }
+  if (tid < D_OUT) atomicAdd(&colsum[tid], csum);
+}
+
 template <int NCT>
 static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, int rows_per_batch, int64_t batch_stride,
                              const void* psplit, double* gram, double* colsum, hipStream_t st) {
@@ -397,6 +604,16 @@ static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, int rows_per
   const size_t z_bytes = (size_t)TM2 * (D_OUT + 16) * 4 + (size_t)D_OUT * 12;     // z tile + fp32 mean + fp64 w
   const size_t lds = p_bytes > z_bytes ? p_bytes : z_bytes;
   const int64_t ntiles = (rows + TM2 - 1) / TM2;
+  // 256-row tiles once every CU would get more than one 128-row tile (BASD_TOKEN_GRAM_T256=0: always 128, A/B timing)
+  const char* env = getenv("BASD_TOKEN_GRAM_T256");
+  if (ntiles > 256 && !(env && env[0] == '0')) {
+    const int64_t nt2 = (rows + 2 * TM2 - 1) / (2 * TM2);
+    const int grid2 = (int)(nt2 < 256 ? nt2 : 256);
+    allow_full_lds((const void*)token_gram_bf16x3_t256_kernel<NCT>);
+    hipLaunchKernelGGL((token_gram_bf16x3_t256_kernel<NCT>), dim3(grid2), dim3(256), lds, st, (const unsigned short*)x, rows,
+                       d_in, rows_per_batch, batch_stride, (const unsigned short*)psplit, gram, colsum);
+    return;
+  }
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
   allow_full_lds((const void*)token_gram_bf16x3_kernel<NCT>);
   hipLaunchKernelGGL((token_gram_bf16x3_kernel<NCT>), dim3(grid), dim3(256), lds, st, (const unsigned short*)x, rows,
