@@ -485,8 +485,11 @@ class _SelectorWeightsFn(torch.autograd.Function):
             grads = []
             for i in range(E):
                 s = student[i]
-                centred = s.float() - s.float().mean(dim=(0, 1), keepdim=True)
-                grads.append((centred.reshape(-1, s.shape[-1]) @ w_tok[i]).reshape(s.shape).to(s.dtype))
+                # (s - mean) W = s W - mean W: one fp32 copy of the tokens, the centring as the GEMM's bias row (the
+                # explicit centred copy was two more passes over the [B N, D] tokens per extraction point)
+                sf = s.float().reshape(-1, s.shape[-1])
+                row = -(sf.mean(dim=0, keepdim=True) @ w_tok[i])
+                grads.append(torch.addmm(row, sf, w_tok[i]).reshape(s.shape).to(s.dtype))
             return (g_lt, None, None, None, None, None, None, None, *grads)
         g_pre = wts * (g_w - (wts * g_w).sum(dim=1, keepdim=True))
         if g_pre_out is not None:
