@@ -3,13 +3,17 @@ import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import basd_amd._native as nat
 
-def timeit(f, it=3):
+def timeit(f, it=7):
+    """median over `it` device-event brackets (a host-side stall of the allocator / runtime once showed up as a 22 ms
+    'launch' in the mean of three wall-clock iterations)"""
     f(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(it):
-        f()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / it * 1e3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); f(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
 
 for batch, n in [(1024, 192), (4, 192), (24, 192), (48, 192), (48, 64)]:
     g = torch.Generator().manual_seed(n)
