@@ -404,13 +404,15 @@ def attention_fwd_supported(t, hd):
     return hd == 64 and 1 <= t <= 272
 
 
-def attention_fwd(qkv, heads, head_dim, scale, want_importance=False, want_lse=False):
+def attention_fwd(qkv, heads, head_dim, scale, want_importance=False, want_lse=False, query_mean=False):
     b, t, _ = qkv.shape
     x = qkv.reshape(b, t, 3, heads, head_dim).permute(2, 0, 3, 1, 4).float()
     q, k, v = x[0], x[1], x[2]
     logits = (q @ k.transpose(-1, -2)) * scale
     p = logits.softmax(dim=-1)
     out = (p.to(torch.bfloat16).float() @ v).transpose(1, 2).reshape(b, t, heads * head_dim).to(torch.bfloat16)
+    if want_importance and query_mean:           # teachers without a CLS token: the map averaged over heads and queries
+        return out, p.mean(dim=(1, 2))
     imp = cls_importance(qkv, heads, head_dim, scale) if want_importance else None
     if want_lse:
         return out, imp, torch.logsumexp(logits, dim=-1)
