@@ -18,17 +18,65 @@ trainer.optimizer.train(); trainer.model.train()
 trainer.overlap_teacher_stats = trainer.overlap_teacher_forward = False
 for _ in range(2):
     trainer.train_step(batch); torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
-    trainer.train_step(batch); torch.cuda.synchronize()
-rows = []
-for ka in prof.key_averages(group_by_stack_n=12, group_by_input_shape=True):
-    t = getattr(ka, "self_device_time_total", 0) or getattr(ka, "self_cuda_time_total", 0)
-    if t <= 0:
+from torch.profiler import profile, ProfilerActivity, record_function
+import functools
+import basd_amd.losses.functional as BF
+import basd_amd.losses.combined as BC
+
+
+def label(obj, name, tag):
+    fn = getattr(obj, name)
+    raw = fn.__func__ if isinstance(fn, staticmethod) else fn
+    @functools.wraps(raw)
+    def wrapped(*a, **k):
+        with record_function("L:" + tag):
+            return raw(*a, **k)
+    setattr(obj, name, staticmethod(wrapped) if isinstance(obj, type) and name in ("forward", "backward") else wrapped)
+
+
+for cls, tag in ((BF._SelectorWeightsFn, "selector"), (BF._MixFn, "mix"), (BF._ProcrustesFn, "procrustes")):
+    label(cls, "forward", tag + ".fwd")
+    label(cls, "backward", tag + ".bwd")
+for fname in ("student_frames", "teacher_frames", "selector_weights", "mix_layers", "procrustes_all"):
+    if hasattr(BF, fname):
+        label(BF, fname, fname)
+label(trainer.model, "forward", "student.forward")
+label(trainer.basd_loss, "forward", "basd_loss.forward")
+label(trainer, "_teacher_branch", "teacher_branch")
+
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with record_function("L:step"):
+        trainer.train_step(batch); torch.cuda.synchronize()
+
+import collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+per_label = collections.defaultdict(float)
+for ev in prof.events():
+    ks = getattr(ev, "kernels", None)
+    if not ks:
         continue
-    frame = next((f for f in ka.stack if "distillation_amd" in f or "basd_amd" in f), ka.stack[0] if ka.stack else "?")
-    rows.append((t, ka.count, ka.key[:44], str(ka.input_shapes)[:64], frame.strip()[-100:]))
-rows.sort(key=lambda r: -r[0])
-print(f"total self device time: {sum(r[0] for r in rows) / 1e3:.2f} ms")
-for t, n, name, shapes, frame in rows[:90]:
-    print(f"{t / 1e3:7.3f} ms  x{n:3d}  {name:44s} {shapes:64s} {frame}")
+    lab, q = "?", ev
+    while q is not None:
+        if q.name.startswith("L:") and q.name != "L:step":
+            lab = q.name[2:]
+            break
+        q = q.cpu_parent
+    if lab == "?":
+        q = ev
+        while q is not None:
+            if q.name.endswith("Backward") or q.name.startswith("autograd::engine"):
+                lab = "autograd:" + q.name[:40]
+                break
+            q = q.cpu_parent
+    for kq in ks:
+        if "basd::" in kq.name:
+            continue
+        agg[(lab, ev.name[:36], kq.name[:60])][0] += 1
+        agg[(lab, ev.name[:36], kq.name[:60])][1] += kq.duration
+        per_label[lab] += kq.duration
+print("non-basd device time by label (us):")
+for lab, t in sorted(per_label.items(), key=lambda kv: -kv[1]):
+    print(f"  {t:9.1f}  {lab}")
+print()
+for (lab, op, kn), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:80]:
+    print(f"{t:8.1f} us x{n:3d}  [{lab:28s}] {op:36s} {kn}")
