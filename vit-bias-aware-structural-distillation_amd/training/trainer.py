@@ -129,10 +129,12 @@ class Trainer:
         # The step runs two streams (teacher branch / student + loss).  A fully persistent GEMM launch holds every CU until
         # it ends, and the other stream's short kernels queue behind it (c2, same box: 41.3 ms per step against 39.5 with
         # workgroups that retire every two tiles; alone on the GPU the persistent form is the fastest: fc1 + GELU 288 vs
-        # 327 us).  basd.gemm_tile_run overrides (0 = fully persistent).
+        # 327 us).  basd.gemm_tile_run overrides (0 = fully persistent).  Round 4, with the shorter loss chain: one tile
+        # per workgroup is better again for the pipelined c2 step (32.53 / 32.59 vs 32.89 / 33.00 ms with two, 33.1 with
+        # three, same box; per-step schedule 35.89 vs 35.99, c3 equal, c4 54.3 vs 54.0).
         # Scoped (``_tile_scope``): only steps that really run two streams see it; evaluation, inference and steps whose
         # side stream was refused keep the fully persistent default.
-        self._gemm_tile_run = int(config.basd.get("gemm_tile_run", 2))
+        self._gemm_tile_run = int(config.basd.get("gemm_tile_run", 1))
         self._graph_pool = None
         self._side = None
         self._graph = None
