@@ -614,6 +614,8 @@ static void launch_tg_bf16x3(const void* x, int64_t rows, int d_in, int rows_per
                        d_in, rows_per_batch, batch_stride, (const unsigned short*)psplit, gram, colsum);
     return;
   }
+  // (measured and rejected: one workgroup per 128-row tile, so that a side-stream launch holds a CU for one tile only --
+  // pipelined c2 step 33.01 / 32.94 ms against 32.75 / 32.68 with at most 256 grid-striding workgroups)
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
   allow_full_lds((const void*)token_gram_bf16x3_kernel<NCT>);
   hipLaunchKernelGGL((token_gram_bf16x3_kernel<NCT>), dim3(grid), dim3(256), lds, st, (const unsigned short*)x, rows,
