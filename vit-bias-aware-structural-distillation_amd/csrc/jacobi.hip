@@ -1446,6 +1446,9 @@ __global__ __launch_bounds__(16 * LANES) __attribute__((amdgpu_waves_per_eu(OCC,
     const float a = t * (dy * __builtin_amdgcn_rcpf(dx));
     const float b = (sn * c) * (dx * __builtin_amdgcn_rcpf(dy));
     const float dxn = fmaf(-dx, h, dx), dyn = fmaf(dy, hp, dy);
+    // (measured: the six (a, b) pairs through 96 bytes of LDS per slot -- one 8-byte write by the parameter lanes, three
+    // 16-byte broadcast reads by all lanes -- instead of these twelve swizzles: 3.335 vs 3.32 ms per 1024 x 192^2,
+    // 0.97 vs 0.98 for a single matrix: the crossbar operations are not what a round waits for; not kept)
     v2f_rot ab[6];
     ab[0] = (v2f_rot){bcast8<0>(a), bcast8<0>(b)};
     ab[1] = (v2f_rot){bcast8<1>(a), bcast8<1>(b)};
