@@ -748,6 +748,15 @@ def trinv(lwork: torch.Tensor, piv: torch.Tensor, rank: torch.Tensor, skip: torc
 # the Trainer sets 2 while its two-stream pipelined step is in use (a persistent launch holds every CU until it ends and
 # the other stream's short kernels queue behind it: measured 41.3 vs 39.5 ms per c2 step).
 GEMM_TILE_RUN = 0
+# The same for the GEMMs of the TRAINED model that take the persistent kernel (fc1 + GELU forward, fc2 input gradient +
+# GELU backward: basd_gemm_bf16_gelu_fwd / _bwd): they are on the step's own chain, not on the side stream.
+# Fully persistent (0) whatever the scope above says: pipelined c2 step 32.54 / 32.54 ms against 32.77 / 32.82 with one
+# tile per workgroup and 32.65 / 32.60 with two (same box).  BASD_GEMM_TILE_RUN_STUDENT overrides (A/B runs).
+GEMM_TILE_RUN_STUDENT = int(os.environ.get("BASD_GEMM_TILE_RUN_STUDENT", "0"))
+
+
+def _student_tile_run() -> int:
+    return GEMM_TILE_RUN_STUDENT
 
 
 @contextlib.contextmanager
@@ -799,7 +808,7 @@ def gemm_gelu_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None):
     pre = torch.empty(x2.shape[0], n, dtype=torch.bfloat16, device=x.device)
     act = torch.empty_like(pre)
     _check(lib().basd_gemm_bf16_gelu_fwd(_ptr(x2), _ptr(w.contiguous()), _ptr(None if bias is None else bias.contiguous()),
-                                         _ptr(pre), _ptr(act), ctypes.c_int64(x2.shape[0]), n, k, GEMM_TILE_RUN,
+                                         _ptr(pre), _ptr(act), ctypes.c_int64(x2.shape[0]), n, k, _student_tile_run(),
                                          _stream()),
            "basd_gemm_bf16_gelu_fwd")
     return pre.view(*x.shape[:-1], n), act.view(*x.shape[:-1], n)
@@ -819,7 +828,7 @@ def gemm_gelu_bwd(dy: torch.Tensor, wt: torch.Tensor, pre: torch.Tensor) -> torc
     assert pre2.is_contiguous() and pre2.shape[0] == dy2.shape[0]
     out = torch.empty_like(pre2)
     _check(lib().basd_gemm_bf16_gelu_bwd(_ptr(dy2), _ptr(wt.contiguous()), _ptr(pre2), _ptr(out),
-                                         ctypes.c_int64(dy2.shape[0]), n, k, GEMM_TILE_RUN, _stream()),
+                                         ctypes.c_int64(dy2.shape[0]), n, k, _student_tile_run(), _stream()),
            "basd_gemm_bf16_gelu_bwd")
     return out.view(*pre.shape)
 
