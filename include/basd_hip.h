@@ -262,8 +262,10 @@ int basd_bgemm_f64_masked(const void* a, int a_dtype, int64_t a_stride, int lda,
  * tile_run: how many output tiles a workgroup of the persistent kernel (large M, N % 256 == 0, K >= 192) multiplies
  * before it retires: 0 = its whole share (one workgroup per CU for the whole launch: fastest when the GEMM has the GPU
  * to itself), k >= 1 = at most k (the CUs come free every k tiles: for launches that share the GPU with another
- * stream; the pipelined BASD step uses 1 for the frozen teacher's launches and 0 for the student's own).  The results do
- * not depend on it. */
+ * stream; the pipelined BASD step uses 1 for the frozen teacher's launches and 0 for the student's own), k < 0 = fully
+ * persistent on -k (8 .. 32) workgroups per XCD, i.e. the launch leaves the other CUs to another stream for its whole
+ * duration (measured at -16 .. -28: equal to 1 within the noise; -12: the teacher branch becomes the critical path).  The
+ * results do not depend on it. */
 int basd_gemm_bf16(const void* x, const void* w, const void* bias, void* y, int64_t M, int N, int K,
                    int epilogue, int tile_run, void* stream);
 

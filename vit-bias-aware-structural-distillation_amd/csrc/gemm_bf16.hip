@@ -558,7 +558,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ bias,
                                                               unsigned short* aux, unsigned short* __restrict__ Y,
                                                               int M, int N, int K, int tiles_n, int mblocks, int ngroup,
-                                                              int chunk_tiles, int ka) {
+                                                              int chunk_tiles, int ka, int P) {
   // EPI 5 (bf16x3 product, fp32 out): the activation panel has row pitch ka and is walked K / ka times (once per
   // split of the weights, whose rows hold the splits side by side: pitch K = 3 ka); N = columns stored = output pitch.
   extern __shared__ __align__(16) unsigned char g_lds[];
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pring_kernel(const unsigned sho
   // ---- this workgroup's range of the XCD's stream
   // grid = chunks x 8 P: workgroup (chunk c, XCD x, rank i) walks the tiles [c T, (c + 1) T) of block i (T = chunk_tiles;
   // one chunk = fully persistent).  Chunks are dispatched in order as CUs come free.
-  const int P = 32;
+  // P = workgroups per XCD (launcher: 32 = every CU; fewer leave CUs to another stream for the whole launch)
   const int chunk = blockIdx.x / (8 * P), slot_id = blockIdx.x - chunk * (8 * P);
   const int xcd = slot_id & 7, ci = slot_id >> 3;
   const int rb = (mblocks - xcd + 7) >> 3;                  // >= 1 (launcher: mblocks >= 8)
@@ -788,14 +788,17 @@ static void launch_gemm_pring(const void* x, const void* w, const void* bias, vo
                               int tile_run, hipStream_t st, int ka = 0) {
   const int tiles_n = (N + 255) / 256, mblocks = (M + GBM - 1) / GBM;
   const int ngroup = gemm_column_group(tiles_n, 256, K);
+  // tile_run < 0: fully persistent on -tile_run (8 .. 32) workgroups per XCD -- the launch leaves the other CUs alone
+  int P = 32;
+  if (tile_run < 0) { P = -tile_run < 8 ? 8 : (-tile_run > 32 ? 32 : -tile_run); tile_run = 0; }
   const int chunk_tiles = tile_run > 0 ? tile_run : 1 << 20;
-  const int max_block = ((mblocks + 7) / 8 * tiles_n + 31) / 32;
+  const int max_block = ((mblocks + 7) / 8 * tiles_n + P - 1) / P;
   const int chunks = (max_block + chunk_tiles - 1) / chunk_tiles;
-  const int grid = 8 * 32 * chunks;
+  const int grid = 8 * P * chunks;
   allow_full_lds((const void*)gemm_bf16_pring_kernel<EPI>);
   hipLaunchKernelGGL((gemm_bf16_pring_kernel<EPI>), dim3(grid), dim3(512), 5 * 32768, st,
                      (const unsigned short*)x, (const unsigned short*)w, (const unsigned short*)bias,
-                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup, chunk_tiles, ka);
+                     (unsigned short*)aux, (unsigned short*)y, M, N, K, tiles_n, mblocks, ngroup, chunk_tiles, ka, P);
 }
 
 template <int BN, int EPI>
